@@ -1,0 +1,178 @@
+// Short-Weierstrass arithmetic y^2 = x^3 + b (a = 0) in Jacobian coordinates, generic over the
+// coordinate field: G1 over fp (blst_p1 / blst_p1_affine), G2 over fp2 (blst_p2 / blst_p2_affine).
+// Infinity: Jacobian Z = 0; affine all-zero (the reference's vec_is_zero convention,
+// blst_lowlevel.nim:28-44).
+#pragma once
+#include "fp.hpp"
+
+namespace bls {
+
+// field-generic spellings
+BLS_HD fp f_add(const fp& a, const fp& b) { return fp_add(a, b); }
+BLS_HD fp f_sub(const fp& a, const fp& b) { return fp_sub(a, b); }
+BLS_HD fp f_mul(const fp& a, const fp& b) { return fp_mul(a, b); }
+BLS_HD fp f_sqr(const fp& a) { return fp_sqr(a); }
+BLS_HD fp f_neg(const fp& a) { return fp_neg(a); }
+BLS_HD fp f_dbl(const fp& a) { return fp_dbl(a); }
+BLS_HD bool f_is_zero(const fp& a) { return fp_is_zero(a); }
+BLS_HD fp f_select(bool c, const fp& a, const fp& b) { return fp_select(c, a, b); }
+BLS_HD fp2 f_add(const fp2& a, const fp2& b) { return fp2_add(a, b); }
+BLS_HD fp2 f_sub(const fp2& a, const fp2& b) { return fp2_sub(a, b); }
+BLS_HD fp2 f_mul(const fp2& a, const fp2& b) { return fp2_mul(a, b); }
+BLS_HD fp2 f_sqr(const fp2& a) { return fp2_sqr(a); }
+BLS_HD fp2 f_neg(const fp2& a) { return fp2_neg(a); }
+BLS_HD fp2 f_dbl(const fp2& a) { return fp2_dbl(a); }
+BLS_HD bool f_is_zero(const fp2& a) { return fp2_is_zero(a); }
+BLS_HD fp2 f_select(bool c, const fp2& a, const fp2& b) { return fp2_select(c, a, b); }
+template <class F>
+BLS_HD F f_zero();
+template <>
+BLS_HD fp f_zero<fp>() { return fp_zero(); }
+template <>
+BLS_HD fp2 f_zero<fp2>() { return fp2_zero(); }
+template <class F>
+BLS_HD F f_one();
+template <>
+BLS_HD fp f_one<fp>() { return fp_one(); }
+template <>
+BLS_HD fp2 f_one<fp2>() { return fp2_one(); }
+
+template <class F>
+struct aff {
+    F x, y;
+};
+template <class F>
+struct jac {
+    F x, y, z;
+};
+using g1_aff = aff<fp>;
+using g1_jac = jac<fp>;
+using g2_aff = aff<fp2>;
+using g2_jac = jac<fp2>;
+
+template <class F>
+BLS_HD bool aff_is_inf(const aff<F>& p) { return f_is_zero(p.x) & f_is_zero(p.y); }
+template <class F>
+BLS_HD bool jac_is_inf(const jac<F>& p) { return f_is_zero(p.z); }
+template <class F>
+BLS_HD jac<F> jac_inf() { return jac<F>{f_zero<F>(), f_zero<F>(), f_zero<F>()}; }
+template <class F>
+BLS_HD jac<F> jac_from_aff(const aff<F>& p) {
+    bool inf = aff_is_inf(p);
+    return jac<F>{p.x, p.y, f_select(inf, f_zero<F>(), f_one<F>())};
+}
+template <class F>
+BLS_HD jac<F> jac_neg(const jac<F>& p) { return jac<F>{p.x, f_neg(p.y), p.z}; }
+template <class F>
+BLS_HD jac<F> jac_select(bool c, const jac<F>& a, const jac<F>& b) {
+    return jac<F>{f_select(c, a.x, b.x), f_select(c, a.y, b.y), f_select(c, a.z, b.z)};
+}
+
+// dbl-2009-l (a = 0): 2M + 5S.  Z = 0 or Y = 0 give Z3 = 0.
+template <class F>
+BLS_HDN jac<F> jac_dbl(const jac<F>& p) {
+    F A = f_sqr(p.x);
+    F B = f_sqr(p.y);
+    F C = f_sqr(B);
+    F D = f_sub(f_sub(f_sqr(f_add(p.x, B)), A), C);
+    D = f_dbl(D);
+    F E = f_add(f_dbl(A), A);
+    F Fq = f_sqr(E);
+    jac<F> r;
+    r.x = f_sub(Fq, f_dbl(D));
+    F C8 = f_dbl(f_dbl(f_dbl(C)));
+    r.y = f_sub(f_mul(E, f_sub(D, r.x)), C8);
+    r.z = f_dbl(f_mul(p.y, p.z));
+    return r;
+}
+
+// Jacobian + affine, complete (handles infinity operands, P == Q, P == -Q).
+template <class F>
+BLS_HDN jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
+    bool p_inf = jac_is_inf(p);
+    bool q_inf = aff_is_inf(q);
+    F Z1Z1 = f_sqr(p.z);
+    F U2 = f_mul(q.x, Z1Z1);
+    F S2 = f_mul(f_mul(q.y, p.z), Z1Z1);
+    F H = f_sub(U2, p.x);
+    F rr = f_sub(S2, p.y);
+    bool h0 = f_is_zero(H), r0 = f_is_zero(rr);
+    if (!p_inf && !q_inf && h0 && r0) return jac_dbl(p);
+    F HH = f_sqr(H);
+    F HHH = f_mul(H, HH);
+    F V = f_mul(p.x, HH);
+    jac<F> r;
+    r.x = f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V));
+    r.y = f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH));
+    r.z = f_mul(p.z, H);   // = 0 when P == -Q
+    r = jac_select(q_inf, p, r);
+    r = jac_select(p_inf, jac_from_aff(q), r);
+    return r;
+}
+
+// Jacobian + Jacobian, complete.
+template <class F>
+BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
+    bool p_inf = jac_is_inf(p);
+    bool q_inf = jac_is_inf(q);
+    F Z1Z1 = f_sqr(p.z);
+    F Z2Z2 = f_sqr(q.z);
+    F U1 = f_mul(p.x, Z2Z2);
+    F U2 = f_mul(q.x, Z1Z1);
+    F S1 = f_mul(f_mul(p.y, q.z), Z2Z2);
+    F S2 = f_mul(f_mul(q.y, p.z), Z1Z1);
+    F H = f_sub(U2, U1);
+    F rr = f_sub(S2, S1);
+    bool h0 = f_is_zero(H), r0 = f_is_zero(rr);
+    if (!p_inf && !q_inf && h0 && r0) return jac_dbl(p);
+    F HH = f_sqr(H);
+    F HHH = f_mul(H, HH);
+    F V = f_mul(U1, HH);
+    jac<F> r;
+    r.x = f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V));
+    r.y = f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH));
+    r.z = f_mul(f_mul(p.z, q.z), H);
+    r = jac_select(q_inf, p, r);
+    r = jac_select(p_inf, q, r);
+    return r;
+}
+
+// [k]P for a 64-bit scalar, affine base; left-to-right double-and-add.  Not constant time: the
+// blinding scalars are public (blst_min_pubkey_sig_core.nim:531-541 rationale).
+template <class F>
+BLS_HDN jac<F> jac_mul_u64(const aff<F>& p, uint64_t kk) {
+    jac<F> acc = jac_inf<F>();
+    for (int i = 63; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((kk >> i) & 1) acc = jac_add_aff(acc, p);
+    }
+    return acc;
+}
+
+// [k]P for Jacobian base
+template <class F>
+BLS_HDN jac<F> jac_mul_u64_jac(const jac<F>& p, uint64_t kk) {
+    jac<F> acc = jac_inf<F>();
+    for (int i = 63; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((kk >> i) & 1) acc = jac_add(acc, p);
+    }
+    return acc;
+}
+
+BLS_HD g1_aff g1_aff_load(const uint8_t* p) { return g1_aff{fp_load_le(p), fp_load_le(p + 48)}; }
+BLS_HD g2_aff g2_aff_load(const uint8_t* p) { return g2_aff{fp2_load_le(p), fp2_load_le(p + 96)}; }
+BLS_HD void g1_jac_store(uint8_t* p, const g1_jac& a) {
+    fp_store_le(p, a.x);
+    fp_store_le(p + 48, a.y);
+    fp_store_le(p + 96, a.z);
+}
+BLS_HD g1_jac g1_jac_load(const uint8_t* p) { return g1_jac{fp_load_le(p), fp_load_le(p + 48), fp_load_le(p + 96)}; }
+BLS_HD void g2_jac_store(uint8_t* p, const g2_jac& a) {
+    fp2_store_le(p, a.x);
+    fp2_store_le(p + 96, a.y);
+    fp2_store_le(p + 192, a.z);
+}
+BLS_HD g2_jac g2_jac_load(const uint8_t* p) { return g2_jac{fp2_load_le(p), fp2_load_le(p + 96), fp2_load_le(p + 192)}; }
+
+}  // namespace bls

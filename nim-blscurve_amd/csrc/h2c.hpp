@@ -1,0 +1,150 @@
+// hash_to_curve for G2, suite BLS12381G2_XMD:SHA-256_SSWU_RO_ (RFC 9380), inversion-free:
+// replaces blst_hash_to_g2 / the hash part of blst_pairing_chk_n_mul_n_aggr_pk_in_g1
+// (reference blst_abi.nim:383, 504-507; call site blst_min_pubkey_sig_core.nim:558-568).
+// Output stays Jacobian: the Miller loop consumes projective Q, so no field inversion per tuple.
+#pragma once
+#include "curve.hpp"
+#include "sha256.hpp"
+
+namespace bls {
+
+// 64 big-endian bytes (as 16 BE words) -> Fp (Montgomery), value mod p.  hi, lo < 2^256 < p.
+BLS_HD fp fp_from_be_words16(const uint32_t* wbe) {
+    fp hi = fp_zero(), lo = fp_zero();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        hi.l[i] = wbe[7 - i];
+        lo.l[i] = wbe[15 - i];
+    }
+    fp him = fp_mul(fp_to_mont(hi), fp_from_const(k::TWO256));
+    return fp_add(him, fp_to_mont(lo));
+}
+
+// expand_message_xmd(msg, dst, 256) -> two Fp2 elements (hash_to_field, count = 2, m = 2, L = 64)
+BLS_HDN void hash_to_field_fp2x2(fp2& u0, fp2& u1, const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+    sha256_ctx c;
+    uint32_t b0[8], bi[8];
+    sha256_begin(c);
+    for (int i = 0; i < 64; i++) sha256_put(c, 0);     // Z_pad
+    sha256_update(c, msg, msg_len);
+    sha256_put(c, 0x01);                                // l_i_b_str = 256
+    sha256_put(c, 0x00);
+    sha256_put(c, 0x00);
+    sha256_update(c, dst, dst_len);
+    sha256_put(c, (uint8_t)dst_len);
+    sha256_end(c, b0);
+    uint32_t uni[64];
+    for (int i = 1; i <= 8; i++) {
+        sha256_begin(c);
+        if (i == 1) {
+            sha256_update_words(c, b0);
+        } else {
+            uint32_t x[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = b0[j] ^ bi[j];
+            sha256_update_words(c, x);
+        }
+        sha256_put(c, (uint8_t)i);
+        sha256_update(c, dst, dst_len);
+        sha256_put(c, (uint8_t)dst_len);
+        sha256_end(c, bi);
+        for (int j = 0; j < 8; j++) uni[(i - 1) * 8 + j] = bi[j];
+    }
+    u0.c0 = fp_from_be_words16(uni);
+    u0.c1 = fp_from_be_words16(uni + 16);
+    u1.c0 = fp_from_be_words16(uni + 32);
+    u1.c1 = fp_from_be_words16(uni + 48);
+}
+
+// (is_square(N/D), y) with y = sqrt(N/D) if square, else sqrt(Z * N/D); Z = -(2+u), norm(Z) = 5.
+// Two Fp exponentiations; the first also yields 1/norm(D).
+BLS_HDN bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
+    fp nN = fp2_norm(N), nD = fp2_norm(D);
+    fp M = fp_mul(nN, nD);
+    fp t = fp_recip_sqrt_pow(M);
+    fp s = fp_mul(M, t);                         // s^2 = M (QR) or -M
+    bool is_sq = fp_eq(fp_sqr(s), M);
+    fp t2 = fp_sqr(t);                           // M * t^2 = +-1
+    fp invM = fp_select(is_sq, t2, fp_neg(t2));
+    fp invnD = fp_mul(nN, invM);
+    fp2 g = fp2_mul_fp(fp2_mul(N, fp2_conj(D)), invnD);
+    fp n = fp_mul(s, invnD);                     // sqrt(norm(g))
+    fp2 gz = fp2_mul(g, fp2_from_const(k::SSWU_Z));
+    fp nz = fp_mul(n, fp_from_const(k::SQRT_M5));
+    g = fp2_select(is_sq, g, gz);
+    n = fp_select(is_sq, n, nz);
+    fp half = fp_from_const(k::HALF);
+    fp d = fp_mul(fp_add(g.c0, n), half);
+    d = fp_select(fp_is_zero(d), g.c0, d);
+    fp t3 = fp_recip_sqrt_pow(d);
+    fp x0 = fp_mul(d, t3);
+    bool qr = fp_eq(fp_sqr(x0), d);
+    fp bh = fp_mul(fp_mul(g.c1, half), t3);
+    y.c0 = fp_select(qr, x0, bh);
+    y.c1 = fp_select(qr, bh, fp_neg(x0));
+    return is_sq;
+}
+
+// Simplified SWU onto E2': y^2 = x^3 + 240u x + 1012(1+u)  (RFC 9380 appendix F.2), Jacobian output.
+BLS_HDN g2_jac sswu_g2(const fp2& u) {
+    const fp2 A = fp2_from_const(k::SSWU_A), B = fp2_from_const(k::SSWU_B), Z = fp2_from_const(k::SSWU_Z);
+    fp2 tv1 = fp2_mul(Z, fp2_sqr(u));
+    fp2 tv2 = fp2_add(fp2_sqr(tv1), tv1);
+    fp2 xn = fp2_mul(B, fp2_add(tv2, fp2_one()));                 // x1 numerator
+    fp2 xd = fp2_select(fp2_is_zero(tv2), fp2_from_const(k::SSWU_ZA), fp2_mul(A, fp2_neg(tv2)));
+    fp2 xd2 = fp2_sqr(xd);
+    fp2 D = fp2_mul(xd2, xd);
+    fp2 N = fp2_add(fp2_mul(fp2_add(fp2_sqr(xn), fp2_mul(A, xd2)), xn), fp2_mul(B, D));
+    fp2 y1;
+    bool is_sq = sqrt_ratio_fp2(y1, N, D);
+    fp2 x2n = fp2_mul(tv1, xn);
+    fp2 y2 = fp2_mul(fp2_mul(tv1, u), y1);
+    fp2 x = fp2_select(is_sq, xn, x2n);
+    fp2 y = fp2_select(is_sq, y1, y2);
+    bool same = fp2_sgn0(u) == fp2_sgn0(y);
+    y = fp2_select(same, y, fp2_neg(y));
+    return g2_jac{fp2_mul(x, xd), fp2_mul(y, D), xd};
+}
+
+// 3-isogeny E2' -> E2 on Jacobian coordinates: (XN(X,Z^2), Y*YN(X,Z^2), Z*(X - xK Z^2))
+BLS_HDN g2_jac iso3_g2(const g2_jac& p) {
+    fp2 z2 = fp2_sqr(p.z), z4 = fp2_sqr(z2), z6 = fp2_mul(z4, z2);
+    fp2 xn = fp2_add(fp2_mul(fp2_from_const(k::ISO_XN3), p.x), fp2_mul(fp2_from_const(k::ISO_XN2), z2));
+    xn = fp2_add(fp2_mul(xn, p.x), fp2_mul(fp2_from_const(k::ISO_XN1), z4));
+    xn = fp2_add(fp2_mul(xn, p.x), fp2_mul(fp2_from_const(k::ISO_XN0), z6));
+    fp2 yn = fp2_add(fp2_mul(fp2_from_const(k::ISO_YN3), p.x), fp2_mul(fp2_from_const(k::ISO_YN2), z2));
+    yn = fp2_add(fp2_mul(yn, p.x), fp2_mul(fp2_from_const(k::ISO_YN1), z4));
+    yn = fp2_add(fp2_mul(yn, p.x), fp2_mul(fp2_from_const(k::ISO_YN0), z6));
+    fp2 d = fp2_sub(p.x, fp2_mul(fp2_from_const(k::ISO_XK), z2));
+    return g2_jac{xn, fp2_mul(p.y, yn), fp2_mul(p.z, d)};
+}
+
+BLS_HD g2_jac g2_psi(const g2_jac& p) {
+    return g2_jac{fp2_mul(fp2_conj(p.x), fp2_from_const(k::PSI_CX)), fp2_mul(fp2_conj(p.y), fp2_from_const(k::PSI_CY)), fp2_conj(p.z)};
+}
+
+// [x]P, x = -0xd201000000010000
+BLS_HD g2_jac g2_mul_x(const g2_jac& p) { return jac_neg(jac_mul_u64_jac(p, k::X_ABS)); }
+
+// h_eff clearing, RFC 9380 appendix G.3: [x^2-x-1]P + [x-1]psi(P) + psi^2(2P)
+BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
+    g2_jac t1 = g2_mul_x(p);
+    g2_jac t2 = g2_psi(p);
+    g2_jac t3 = g2_psi(g2_psi(jac_dbl(p)));
+    t3 = jac_add(t3, jac_neg(t2));
+    t2 = jac_add(t1, t2);
+    t2 = g2_mul_x(t2);
+    t3 = jac_add(t3, t2);
+    t3 = jac_add(t3, jac_neg(t1));
+    return jac_add(t3, jac_neg(p));
+}
+
+BLS_HDN g2_jac hash_to_g2(const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+    fp2 u0, u1;
+    hash_to_field_fp2x2(u0, u1, msg, msg_len, dst, dst_len);
+    g2_jac q0 = iso3_g2(sswu_g2(u0));
+    g2_jac q1 = iso3_g2(sswu_g2(u1));
+    return clear_cofactor_g2(jac_add(q0, q1));
+}
+
+}  // namespace bls

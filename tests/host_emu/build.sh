@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds the CPU execution harness for the product's __host__ __device__ arithmetic (tests only).
+set -e
+cd "$(dirname "$0")"
+mkdir -p _build
+if [ ! -f _build/libemu.so ] || [ emu.hip -nt _build/libemu.so ] || [ -n "$(find ../../nim-blscurve_amd/csrc -name '*.hpp' -newer _build/libemu.so)" ]; then
+  hipcc -O2 -std=c++17 --offload-host-only -fPIC -shared -I ../../nim-blscurve_amd/csrc emu.hip -o _build/libemu.so
+fi

@@ -1,0 +1,44 @@
+// Host-side execution of the product's __host__ __device__ arithmetic, for CPU-only tests in the
+// build container (no GPU there).  TEST INFRASTRUCTURE: never linked into the product library.
+#include "fp.hpp"
+#include "tower.hpp"
+#include "curve.hpp"
+#include "h2c.hpp"
+#include "pairing.hpp"
+using namespace bls;
+extern "C" {
+void emu_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_mul(fp_load_le(a), fp_load_le(b))); }
+void emu_fp_add(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_add(fp_load_le(a), fp_load_le(b))); }
+void emu_fp_sub(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_sub(fp_load_le(a), fp_load_le(b))); }
+void emu_fp_inv(const uint8_t* a, uint8_t* r) { fp_store_le(r, fp_inv(fp_load_le(a))); }
+void emu_fp2_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp2_store_le(r, fp2_mul(fp2_load_le(a), fp2_load_le(b))); }
+void emu_fp2_sqr(const uint8_t* a, uint8_t* r) { fp2_store_le(r, fp2_sqr(fp2_load_le(a))); }
+void emu_fp2_inv(const uint8_t* a, uint8_t* r) { fp2_store_le(r, fp2_inv(fp2_load_le(a))); }
+void emu_sha256(const uint8_t* m, uint32_t n, uint8_t* out) {
+    sha256_ctx c; sha256_begin(c); sha256_update(c, m, n); uint32_t d[8]; sha256_end(c, d);
+    for (int i = 0; i < 8; i++) { out[4*i] = d[i] >> 24; out[4*i+1] = d[i] >> 16; out[4*i+2] = d[i] >> 8; out[4*i+3] = d[i]; }
+}
+void emu_hash_to_field(const uint8_t* m, uint32_t n, const uint8_t* dst, uint32_t dn, uint8_t* out192) {
+    fp2 u0, u1; hash_to_field_fp2x2(u0, u1, m, n, dst, dn); fp2_store_le(out192, u0); fp2_store_le(out192 + 96, u1);
+}
+// u (96 B) -> Jacobian point on E2' (288 B)
+void emu_sswu(const uint8_t* u, uint8_t* out) { g2_jac_store(out, sswu_g2(fp2_load_le(u))); }
+void emu_iso3(const uint8_t* in, uint8_t* out) { g2_jac_store(out, iso3_g2(g2_jac_load(in))); }
+void emu_hash_to_g2(const uint8_t* m, uint32_t n, const uint8_t* dst, uint32_t dn, uint8_t* out) { g2_jac_store(out, hash_to_g2(m, n, dst, dn)); }
+void emu_g1_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g1_jac_store(out, jac_mul_u64(g1_aff_load(p), k)); }
+void emu_g2_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g2_jac_store(out, jac_mul_u64(g2_aff_load(p), k)); }
+void emu_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g1_jac_store(out, jac_add(g1_jac_load(a), g1_jac_load(b))); }
+void emu_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g2_jac_store(out, jac_add(g2_jac_load(a), g2_jac_load(b))); }
+// n pairs of (P Jacobian 144 B, Q Jacobian 288 B) -> final_exp(miller) 576 B
+void emu_pairing_product(const uint8_t* ps, const uint8_t* qs, uint32_t n, uint8_t* out, int do_final_exp) {
+    fp12 L[N_LINES];
+    for (int s = 0; s < N_LINES; s++) L[s] = fp12_one();
+    for (uint32_t i = 0; i < n; i++)
+        miller_lines(g1_jac_load(ps + 144 * i), g2_jac_load(qs + 288 * i), [&](int s, const line_t& l) { L[s] = fp12_mul_by_line(L[s], l); });
+    fp12 f = miller_combine([&](int s) { return L[s]; });
+    if (do_final_exp) f = final_exp(f);
+    fp12_store_le(out, f);
+}
+void emu_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp12_store_le(r, fp12_mul(fp12_load_le(a), fp12_load_le(b))); }
+void emu_final_exp(const uint8_t* a, uint8_t* r) { fp12_store_le(r, final_exp(fp12_load_le(a))); }
+}

@@ -1,0 +1,136 @@
+"""Pins oracle/bls12381_py.py to every byte-level KAT the reference tree holds for this path
+(SURVEY.md section 8c).  Expected values are data copied from the reference's tests:
+tests/priv_to_pub.nim:32-81, tests/priv_to_pub.sage:76-124, tests/eth2_vectors.nim:33-69,
+tests/serialization.nim:19-45."""
+import pytest
+
+import bls12381_py as o
+
+SK_PK = [
+    ("00000000000000000000000000000000000000000000000000000000000003e8", "a60e75190e62b6a54142d147289a735c4ce11a9d997543da539a3db57def5ed83ba40b74e55065f02b35aa1d504c404b"),
+    ("00000000000000000000000000000000000000000000000000000000000003e9", "ae12039459c60491672b6a6282355d8765ba6272387fb91a3e9604fa2a81450cf16b870bb446fc3a3e0a187fff6f8945"),
+    ("00000000000000000000000000000000000000000000000000000000000003ea", "947b327c8a15b39634a426af70c062b50632a744eddd41b5a4686414ef4cd9746bb11d0a53c6c2ff21bbcf331e07ac92"),
+    ("00000000000000000000000000000000000000000000000000000000000003eb", "85fc4ae543ca162474586e76d72c47d0151c3cb7b77e82c87e554abf72548e2e746bc675805b688b5016269e18ff4250"),
+    ("00000000000000000000000000000000000000000000000000000000000003ec", "8caa0de862793e567c6050aa822db2d6cb2b520bc62b6dbcba7e773067ed09c7ba0282d7c20e01500c6c2fa76408aded"),
+    ("47faea55fe00a78306449165c017c9db86411a4c2467b4b89e21323c746406a0", "a18e29d0185a5a6d19edf052ae098fd2924f579b6dfb4905332b8f4fc78adeb3188ad8315bf279a144be026ac08f3441"),
+]
+
+# tests/priv_to_pub.sage:76-124 (sk, x, y, compressed)
+SAGE = [
+    (1000, "60e75190e62b6a54142d147289a735c4ce11a9d997543da539a3db57def5ed83ba40b74e55065f02b35aa1d504c404b", "17ecb08d4bb31b7eeb6581e6808c6abf58958845b917e085baaab098b9a8a3ecc8caf6f1a06c46b0f7812b09aa52e7a0"),
+    (1001, "e12039459c60491672b6a6282355d8765ba6272387fb91a3e9604fa2a81450cf16b870bb446fc3a3e0a187fff6f8945", "18b6c1ed9f45d3cbc0b01b9d038dcecacbd702eb26469a0eb3905bd421461712f67f782b4735849644c1772c93fe3d09"),
+    (1002, "147b327c8a15b39634a426af70c062b50632a744eddd41b5a4686414ef4cd9746bb11d0a53c6c2ff21bbcf331e07ac92", "78c2e9782fa5d9ab4e728684382717aa2b8fad61b5f5e7cf3baa0bc9465f57342bb7c6d7b232e70eebcdbf70f903a45"),
+    (1003, "5fc4ae543ca162474586e76d72c47d0151c3cb7b77e82c87e554abf72548e2e746bc675805b688b5016269e18ff4250", "7c13f661fd28bf1ea1cf51c762dda21547877eedf54e9263b3b5d0923820b58ed81503beb24fc4cd50bd47d9d67d7e"),
+    (1004, "caa0de862793e567c6050aa822db2d6cb2b520bc62b6dbcba7e773067ed09c7ba0282d7c20e01500c6c2fa76408aded", "c7c359be46db8efd81618b29cea252fdbfff8229dd3e3c7f98c10801fdc9bb65403d124b43a934f8a1cf8ca351ee1df"),
+    (1005, "a273fd05323e1381e10e93e683c34647328127020b3507fc8cddc337038e33fbd7a99ef0d2c7b6a278d7f8116162560", "134e59e38d0cdda7464634c997d9f08b7e336bdfa895b764f8c4e24e52e3f46683d8e798ada2d65f055adb4a7bf6c279"),
+    (1006, "fcecff9ae0490f723123822c66f36996d237490d6769ee68f9f7a7da1c6bac8b5c3d0c4348e8ce8fc3d5159f8333484", "86e75481cf86317947ced9b0c52a631a22a213e49b9ea0cd016184d48541e9f2424a5e01a800673b7a2b2601cb77bea"),
+    (1007, "f4ffe81a50cf117069c9a66ad9f2776eeeae94fe02ba2a0f9596cb798f9e5bdf4719fceaa61746ffe2408f25b56d96e", "326c5937def2d0725be78d653b1e107c8faf40fea0759caf640ae0be5c569ef73ecdcc1d8552725f8de69e95f4cf53c"),
+    (1008, "785405f275ee2fd934e83835a79ba651f80b0f432df1b806350dc949c169c60e60767e41faed8eaac5ed0e9e210787c", "c82aaba7cb0db559d0eb9cb1bebb8d9de2ac1bbceda92518b16bdca4be5bda5b219b345ec2b3719fac5891eb3ee531a"),
+    (1009, "ade2091378293a63d55328cef23736f4dbdc49bd3c0787b8c18cd6a8ddc2d42a279242e87b22d1909f3f1d55e5da66", "14f22ce1b5483fa15b71f81d998cbb695a369948214bf7d7c9841c26903cee7b5485bc1331061f1c9c17cce8778b15e"),
+]
+
+POP = [
+    ("263dbd792f5b1be47ed85f8938c0f29586af0d3ac7b977f21c278fe1462040e3",
+     "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a",
+     "b803eb0ed93ea10224a73b6b9c725796be9f5fefd215ef7a5b97234cc956cf6870db6127b7e4d824ec62276078e787db05584ce1adbf076bc0808ca0f15b73d59060254b25393d95dfc7abe3cda566842aaedf50bbb062aae1bbb6ef3b1f77e1"),
+    ("47b8192d77bf871b62e87859d653922725724a5c031afeabc60bcef5ff665138",
+     "b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81",
+     "88bb31b27eae23038e14f9d9d1b628a39f5881b5278c3c6f0249f81ba0deb1f68aa5f8847854d6554051aa810fdf1cdb02df4af7a5647b1aa4afb60ec6d446ee17af24a8a50876ffdaf9bf475038ec5f8ebeda1c1c6a3220293e23b13a9a5d26"),
+    ("328388aff0d4a5b7dc9205abd374e7e98f3cd9f3418edb4eafda5fb16473d216",
+     "b53d21a4cfd562c469cc81514d4ce5a6b577d8403d32a394dc265dd190b47fa9f829fdd7963afdf972e5e77854051f6f",
+     "88873ea58f5017a33facc9bf04efaf5e2f34f7bc9ce564d0481dd469326c04ef43552f50e99de8a13315dcd37a4fb9ef036d1a54e5febf5d20b6aa488f3e3c917e6a96ce6461f609ec7e0a1fd8950380922e46c3654fa7542436603f833462da"),
+]
+
+
+@pytest.mark.parametrize("sk,pk", SK_PK)
+def test_sk_to_pk(sk, pk):
+    assert o.g1_compress(o.sk_to_pk(int(sk, 16))).hex() == pk
+
+
+@pytest.mark.parametrize("sk,x,y", SAGE)
+def test_sage_affine(sk, x, y):
+    p = o.sk_to_pk(sk)
+    assert p == (int(x, 16), int(y, 16))
+
+
+def test_keygen_kat():
+    ikm = bytes.fromhex("93ad7e65dead052a083a910c8b728591464cca56605bb056edfe2b60a63c4899")
+    assert o.keygen(ikm) == int("47faea55fe00a78306449165c017c9db86411a4c2467b4b89e21323c746406a0", 16)
+
+
+def test_sk_ge_r_rejected_values():
+    # tests/priv_to_pub.nim:86-89: r and r+1 are not valid secret keys
+    assert int("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001", 16) == o.R
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_pop_kats(i):
+    sk, pk, proof = POP[i]
+    sk = int(sk, 16)
+    assert o.g1_compress(o.sk_to_pk(sk)).hex() == pk
+    assert o.g2_compress(o.pop_prove(sk)).hex() == proof          # hash-to-G2 + G2 mul + compression
+    pkp = o.g1_decompress(bytes.fromhex(pk))
+    prf = o.g2_decompress(bytes.fromhex(proof))
+    assert o.g1_in_subgroup(pkp) and o.g2_in_subgroup(prf)
+    assert o.pop_verify(pkp, prf)                                   # Miller loop + final exp verdicts
+    wrong = o.g1_decompress(bytes.fromhex(POP[(i + 1) % 3][1]))
+    assert not o.pop_verify(wrong, prf)
+
+
+def test_serialization_kats():
+    assert o.g2_compress(None).hex() == "c" + "0" * 191              # tests/serialization.nim:19-29
+    bad = bytes([217, 149, 255, 97, 73, 133, 236, 43, 248, 34, 30, 10, 15, 45, 82, 72, 243, 179, 53, 17, 27, 17, 248, 180, 7, 92, 200, 153, 11, 3, 111, 137, 124, 171, 29, 218, 191, 246, 148, 57, 160, 50, 232, 129, 81, 90, 72, 161, 110, 138, 243, 116, 0, 88, 125, 180, 67, 153, 194, 181, 117, 152, 166, 147, 13, 77, 15, 91, 33, 50, 140, 199, 150, 10, 15, 10, 209, 165, 38, 57, 56, 114, 175, 29, 49, 11, 11, 126, 55, 189, 170, 46, 218, 240, 189, 144])
+    with pytest.raises(ValueError):
+        o.g2_decompress(bad)                                        # tests/serialization.nim:39-45
+
+
+def test_structure_checks():
+    assert o.g1_in_subgroup(o.G1_GEN) and o.g2_in_subgroup(o.G2_GEN)
+    f = o.miller_loop([(o.G1_GEN, o.G2_GEN)])
+    e = o.final_exp(f)
+    n = o.final_exp_naive(f)
+    assert e == o.f12mul(o.f12mul(n, n), n) and e != o.F12_ONE
+    assert o.pairing(o.g1_mul(o.G1_GEN, 5), o.g2_mul(o.G2_GEN, 7)) == o.f12pow(e, 35)
+    h = o.hash_to_g2(b"abc")
+    assert o.g2_in_subgroup(h)
+    u = o.hash_to_field_fp2(b"abc", o.DST_SIG)
+    slow = o.clear_cofactor_g2_slow(o.iso3_g2(o.ec_add(o.FP2, o.sswu_g2(u[0]), o.sswu_g2(u[1]), o.SSWU_A)))
+    assert slow == h
+
+
+def test_parallel_chunks_and_scalars():
+    # parallel_chunks.nim:42-66
+    assert o.parallel_chunks(4, 17) == [(0, 5), (5, 4), (9, 4), (13, 4)]
+    assert o.parallel_chunks(4, 2) == [(0, 1), (1, 1)]
+    rnd = o.sha256(b"Mr F was here")
+    assert rnd.hex().startswith("3e894140") and rnd.hex().endswith("d3bd1592")   # t_batch_verifier.nim:60
+    rs = o.blinding_scalars(rnd, 5)
+    seed = o.sha256(rnd)
+    for r in rs:
+        seed = o.sha256(seed)
+        assert r == int.from_bytes(seed[:8], "little")
+    rp = o.blinding_scalars(rnd, 5, 4)
+    assert rp[0] == int.from_bytes(o.sha256(o.sha256(rnd + (0).to_bytes(8, "little")))[:8], "little")
+    assert rp[1] == int.from_bytes(o.sha256(o.sha256(o.sha256(rnd + (0).to_bytes(8, "little"))))[:8], "little")
+    assert rp[2] == int.from_bytes(o.sha256(o.sha256(rnd + (1).to_bytes(8, "little")))[:8], "little")
+
+
+def test_batch_golden_verdicts_match_reference_expectations():
+    """The fixture's recorded verdicts are the booleans tests/t_batch_verifier.nim asserts."""
+    from util import golden
+    g = golden("batch")
+    exp = {"single": True, "two": True, "n15": True, "n16": True, "n17": True, "wrong_sig": False,
+           "forged_pair": False, "forged_among_many": False, "same_msg_100": True, "inf_pk": False}
+    got = {c["name"]: c["expect"] for c in g["cases"]}
+    for k, v in exp.items():
+        assert got[k] == v
+    # re-verify two small ones end to end with the oracle (cheap)
+    for c in g["cases"]:
+        if c["name"] in ("two", "wrong_sig"):
+            raw = bytes.fromhex(c["sets"])
+            sets = []
+            for i in range(c["n"]):
+                r = raw[320 * i:320 * i + 320]
+                sets.append((o.g1_from_blst_affine(r[:96]), r[96:128], o.g2_from_blst_affine(r[128:])))
+            assert o.batch_verify(sets, bytes.fromhex(c["rnd"])) == c["expect"]
+            assert o.batch_verify(sets, bytes.fromhex(c["rnd"]), 4) == c["expect"]
