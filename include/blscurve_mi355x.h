@@ -1,0 +1,100 @@
+/* C ABI of the MI355X-native BLS12-381 batch-verification path.
+ *
+ * Drop-in boundary: these entry points are what nim-blscurve's batch layer would bind (importc)
+ * instead of driving BLST tuple by tuple.  Every function cites the reference interface it
+ * replaces (paths relative to the nim-blscurve tree).  Plain pointers and sizes only.
+ *
+ * Data layouts are the reference's in-memory ones (BLST structs, Montgomery limbs R = 2^384,
+ * little-endian u64 x 6 per Fp; blscurve/blst/blst_abi.nim:87-122):
+ *   blst_p1_affine  96 B (x, y)          blst_p1  144 B (x, y, z)   Jacobian
+ *   blst_p2_affine 192 B (x.c0,x.c1,y.c0,y.c1)   blst_p2 288 B      Jacobian
+ *   blst_fp12      576 B
+ *   SignatureSet   320 B = pubkey @0 (96) | message @96 (32) | signature @128 (192)
+ *                  (blscurve/bls_batch_verifier.nim:34; affine infinity = all-zero bytes)
+ *
+ * Return convention: 1 = verified (Nim `true`), 0 = not verified (Nim `false`), negative = runtime
+ * failure (no GPU, HIP error, capacity); the reference API only has bool, the Nim shim maps <0 to
+ * a Defect.  The library never falls back to a CPU path.
+ */
+#ifndef BLSCURVE_MI355X_H
+#define BLSCURVE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_BLS_SIGSET_BYTES 320
+#define MI355_BLS_FP12_BYTES 576
+#define MI355_BLS_P1_BYTES 144
+#define MI355_BLS_P2_BYTES 288
+
+#define MI355_BLS_ERR_HIP (-1)       /* a HIP call failed; see mi355_bls_last_error() */
+#define MI355_BLS_ERR_CAPACITY (-2)  /* n exceeds the context's capacity */
+#define MI355_BLS_ERR_ARG (-3)
+
+typedef struct mi355_bls_ctx mi355_bls_ctx;
+
+/* BatchedBLSVerifierCache.init / init(tp) (bls_batch_verifier.nim:108-119): persistent device
+ * workspace sized for batches of up to max_sets triplets on HIP device `device`.  One context per
+ * concurrent caller, reusable across calls (bls_batch_verifier.nim:389-391). */
+int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets);
+void mi355_bls_ctx_destroy(mi355_bls_ctx* ctx);
+const char* mi355_bls_last_error(void);
+
+/* Taskpool.numThreads analogue (bls_batch_verifier.nim:316): the number of blinding-scalar hash
+ * chains ("virtual threads") B = min(n, num_threads) the parallel path splits a batch into; chunk c
+ * is seeded SHA256(rnd || LE64(c)) exactly as processSingleChunk does (:333-336).  Default 4096. */
+int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* ctx, uint32_t num_threads);
+
+/* batchVerifyParallel / batchVerify raw-pointer overloads (bls_batch_verifier.nim:296-302,420-426):
+ * sets = n x 320-byte SignatureSet records in HOST memory, rnd = secureRandomBytes. n == 0 -> 0. */
+int mi355_bls_batch_verify(mi355_bls_ctx* ctx, const void* sets, size_t n, const uint8_t rnd[32]);
+
+/* batchVerifySerial (bls_batch_verifier.nim:121-160): same check with the serial scalar chain
+ * (seed = SHA256(rnd), one chain over the whole batch). */
+int mi355_bls_batch_verify_serial(mi355_bls_ctx* ctx, const void* sets, size_t n, const uint8_t rnd[32]);
+
+/* Same as mi355_bls_batch_verify with the records already resident in device memory (HBM) and
+ * work enqueued on `stream` (hipStream_t, may be NULL); synchronises the stream before returning. */
+int mi355_bls_batch_verify_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream);
+
+/* Multi-GPU sharding (replaces processSingleChunk + merge, bls_batch_verifier.nim:326-369).
+ * The global batch of n_total sets is cut into B = min(n_total, num_threads) chunks by
+ * parallel_chunks (parallel_chunks.nim:42-66); this call processes chunks [chunk_lo, chunk_hi),
+ * whose records start at d_sets (device memory), and returns the shard's committed pairing state:
+ *   out_fp12 = prod_{i in shard} ML(H(m_i), [r_i]PK_i) * ML(sum [r_i]S_i, -G1)   (576 B, pre final-exp)
+ *   *out_ok  = 0 if an update failed (infinity public key), else 1.
+ * The signature-side pair is folded per shard, so merging shards is an Fp12 product only
+ * (blst_pairing_merge, blst_abi.nim:508). */
+int mi355_bls_batch_shard_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
+                                 const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok);
+
+/* merge + finalVerify (blst_min_pubkey_sig_core.nim:657-672): product of k shard states (host
+ * memory, k x 576 B), one final exponentiation on the device, == 1. */
+int mi355_bls_finalverify_shards(mi355_bls_ctx* ctx, const uint8_t* fp12s, size_t k);
+
+/* Helper: tuple range [*first, *first + *count) covered by chunks [chunk_lo, chunk_hi) of a batch of
+ * n_total sets split into num_threads chunks (parallel_chunks.nim:42-66). */
+void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t chunk_lo, uint32_t chunk_hi, size_t* first, size_t* count);
+
+/* Stage outputs of the LAST batch call on this context, for parity tests (no reference
+ * counterpart: BLST keeps these inside blst_pairing).  `what`:
+ *   0: blinding scalars r_i           n x 8 B  (LE u64)
+ *   1: H(m_i) Jacobian                n x 288 B (blst_p2)
+ *   2: [r_i]PK_i Jacobian             n x 144 B (blst_p1)
+ *   3: sum [r_i]S_i Jacobian          288 B
+ *   4: GT after final exponentiation  576 B   (f^(3 (p^12-1)/r))
+ *   5: Miller-loop product before final exponentiation 576 B */
+int mi355_bls_fetch_stage(mi355_bls_ctx* ctx, int what, void* out, size_t out_bytes);
+
+/* Kernel timing of the last batch call, ms per stage measured with HIP events on the call's stream:
+ * out[0..7] = blinding, hash_to_g2, pk_mul, sig_mul+sum, miller_lines, line_products, final, total. */
+int mi355_bls_last_timings(mi355_bls_ctx* ctx, float out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+"""Host-side mirror of nim-blscurve's batch-verifier API over the MI355X C ABI.
+
+Python stands in for the Nim host layer (no Nim toolchain in the build image); names, argument
+meaning and error behaviour follow ``blscurve/bls_batch_verifier.nim``:
+
+  SignatureSet            (pubkey, message[32], signature) triplet, 320-byte record  (:34)
+  BatchedBLSVerifierCache reusable per-caller scratch -> persistent device workspace  (:62-69,:108-119)
+  batchVerifySerial       (:121-177)      batchVerifyParallel (:296-416)      batchVerify (:420-495)
+
+The compute lives entirely in ``libblscurve_mi355x.so`` (hand-written HIP, gfx950).  There is no
+CPU fallback: importing works without a GPU (so symbols can be checked), every compute call
+raises ``BlsGpuError`` if the library or a GPU is missing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblscurve_mi355x.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "blscurve_mi355x.h"))
+
+SIGSET_BYTES = 320
+DEFAULT_NUM_THREADS = 4096
+
+
+class BlsGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The C-ABI library; raises loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BlsGpuError("HIP extension missing: %s (run nim-blscurve_amd/build.sh); no CPU fallback exists" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+        L.mi355_bls_ctx_create.argtypes = [ctypes.POINTER(vp), i32, sz]
+        L.mi355_bls_ctx_destroy.argtypes = [vp]
+        L.mi355_bls_ctx_destroy.restype = None
+        L.mi355_bls_last_error.restype = ctypes.c_char_p
+        L.mi355_bls_ctx_set_num_threads.argtypes = [vp, u32]
+        L.mi355_bls_batch_verify.argtypes = [vp, vp, sz, ctypes.c_char_p]
+        L.mi355_bls_batch_verify_serial.argtypes = [vp, vp, sz, ctypes.c_char_p]
+        L.mi355_bls_batch_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp]
+        L.mi355_bls_batch_shard_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, ctypes.c_char_p, ctypes.POINTER(i32)]
+        L.mi355_bls_finalverify_shards.argtypes = [vp, ctypes.c_char_p, sz]
+        L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.mi355_bls_chunk_range.restype = None
+        L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
+        L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise BlsGpuError("mi355_bls error %d: %s" % (rc, lib().mi355_bls_last_error().decode()))
+    return rc
+
+
+def pack_signature_sets(sets):
+    """[(pubkey96, message32, signature192)] -> contiguous 320-byte records (the Nim tuple layout)."""
+    out = bytearray()
+    for pk, msg, sig in sets:
+        if len(pk) != 96 or len(msg) != 32 or len(sig) != 192:
+            raise ValueError("SignatureSet = (96-byte blst_p1_affine, 32-byte message, 192-byte blst_p2_affine)")
+        out += pk + msg + sig
+    return bytes(out)
+
+
+def _as_records(input_):
+    if isinstance(input_, (bytes, bytearray, memoryview)):
+        b = bytes(input_)
+        if len(b) % SIGSET_BYTES:
+            raise ValueError("record buffer is not a multiple of 320 bytes")
+        return b
+    return pack_signature_sets(input_)
+
+
+def chunk_range(n_total, num_threads, chunk_lo, chunk_hi):
+    """Tuple range of chunks [chunk_lo, chunk_hi) (parallel_chunks.nim:42-66)."""
+    first, count = ctypes.c_size_t(), ctypes.c_size_t()
+    lib().mi355_bls_chunk_range(n_total, num_threads, chunk_lo, chunk_hi, ctypes.byref(first), ctypes.byref(count))
+    return first.value, count.value
+
+
+class BatchedBLSVerifierCache:
+    """bls_batch_verifier.nim:62-69.  ``init(numThreads=...)`` mirrors ``init(tp: Taskpool)``:
+    numThreads is the number of blinding chains the parallel path uses (B = min(n, numThreads))."""
+
+    def __init__(self, max_sets=65536, numThreads=DEFAULT_NUM_THREADS, device=0):
+        self._h = ctypes.c_void_p()
+        self.max_sets = max_sets
+        self.numThreads = numThreads
+        _check(lib().mi355_bls_ctx_create(ctypes.byref(self._h), device, max_sets))
+        _check(lib().mi355_bls_ctx_set_num_threads(self._h, numThreads))
+
+    @classmethod
+    def init(cls, max_sets=65536, numThreads=DEFAULT_NUM_THREADS, device=0):
+        return cls(max_sets, numThreads, device)
+
+    def close(self):
+        if self._h:
+            lib().mi355_bls_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- stage outputs of the last call (parity tests) --
+    def fetch(self, what, nbytes):
+        b = ctypes.create_string_buffer(nbytes)
+        _check(lib().mi355_bls_fetch_stage(self._h, what, b, nbytes))
+        return b.raw
+
+    def timings(self):
+        t = (ctypes.c_float * 8)()
+        _check(lib().mi355_bls_last_timings(self._h, t))
+        names = ["blinding", "hash_to_g2", "pk_mul", "sig_mul_sum", "miller_lines", "line_products", "final", "total"]
+        return dict(zip(names, list(t)))
+
+    # -- device-resident entry points --
+    def verify_device(self, d_ptr, n, secureRandomBytes, stream=0):
+        return bool(_check(lib().mi355_bls_batch_verify_device(self._h, d_ptr, n, bytes(secureRandomBytes), stream)))
+
+    def shard_device(self, d_ptr, n_total, chunk_lo, chunk_hi, secureRandomBytes, stream=0):
+        out = ctypes.create_string_buffer(576)
+        ok = ctypes.c_int()
+        _check(lib().mi355_bls_batch_shard_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, bytes(secureRandomBytes), stream, out, ctypes.byref(ok)))
+        return out.raw, bool(ok.value)
+
+    def finalverify_shards(self, states):
+        blob = b"".join(states)
+        return bool(_check(lib().mi355_bls_finalverify_shards(self._h, blob, len(states))))
+
+
+def batchVerifySerial(cache, input_, secureRandomBytes):
+    """bls_batch_verifier.nim:121-160.  Empty input -> False."""
+    rec = _as_records(input_)
+    n = len(rec) // SIGSET_BYTES
+    if n == 0:
+        return False
+    return bool(_check(lib().mi355_bls_batch_verify_serial(cache._h, rec, n, bytes(secureRandomBytes))))
+
+
+def batchVerifyParallel(cache, input_, secureRandomBytes):
+    """bls_batch_verifier.nim:296-416."""
+    rec = _as_records(input_)
+    n = len(rec) // SIGSET_BYTES
+    if n == 0:
+        return False
+    return bool(_check(lib().mi355_bls_batch_verify(cache._h, rec, n, bytes(secureRandomBytes))))
+
+
+def batchVerify(cache, input_, secureRandomBytes):
+    """bls_batch_verifier.nim:420-495: parallel iff numThreads > 1 and n >= 3, else serial."""
+    rec = _as_records(input_)
+    n = len(rec) // SIGSET_BYTES
+    if cache.numThreads > 1 and n >= 3:
+        return batchVerifyParallel(cache, rec, secureRandomBytes)
+    return batchVerifySerial(cache, rec, secureRandomBytes)

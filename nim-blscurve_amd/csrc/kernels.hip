@@ -1,0 +1,614 @@
+// HIP kernels + C ABI of the MI355X batch-verification path (gfx950 only).
+//
+// Pipeline for one batch of n SignatureSets (reference call stack: bls_batch_verifier.nim:296-371 ->
+// blst_min_pubkey_sig_core.nim:476-568,649-672 -> BLST):
+//   k_blind      one lane per blinding chain ("virtual thread"): r_i         (core :497-507,:545-556)
+//   k_hash       one lane per tuple: H_i = hash_to_G2(msg_i), Jacobian       (blst hash part)
+//   k_pkmul      one lane per tuple: [r_i]PK_i, Jacobian; infinity-pk flag    (blst pk part)
+//   k_sigmul     one lane per tuple: [r_i]S_i, wave-shuffle sum -> partials   (blst sig part)
+//   k_sigsum     partials -> AggrSign; appended as pair n with P = -G1        (finalverify's extra pair)
+//   k_lines      one lane per pair: 68 Miller lines -> HBM, step-major SoA    (miller_loop_n)
+//   k_lineprod   (step, pair-range) grid: per-lane sparse products, wave-shuffle Fp12 product tree
+//   k_lineprod2  per step: product of the range partials -> L_s
+//   k_final      Horner over the 68 L_s, conjugate, [shard merge], final exponentiation, == 1
+// Intermediates live in HBM as structure-of-arrays of 16-byte limb groups so that lane i's
+// loads/stores of one limb group are contiguous across the wave (coalesced dwordx4).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/blscurve_mi355x.h"
+#include "h2c.hpp"
+#include "pairing.hpp"
+
+using namespace bls;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                \
+            return MI355_BLS_ERR_HIP;                                                              \
+        }                                                                                          \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+struct dst_t {
+    uint8_t b[64];
+    uint32_t len;
+};
+
+// ------------------------------------------------------------------------------------------
+// SoA accessors: plane p of element i lives at base[(3p+q)*stride + i], q = 0..2 (uint4 each)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ fp soa_ld(const uint4* base, size_t stride, uint32_t plane, size_t i) {
+    fp r;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        uint4 v = base[(size_t)(plane * 3 + q) * stride + i];
+        r.l[4 * q] = v.x;
+        r.l[4 * q + 1] = v.y;
+        r.l[4 * q + 2] = v.z;
+        r.l[4 * q + 3] = v.w;
+    }
+    return r;
+}
+__device__ __forceinline__ void soa_st(uint4* base, size_t stride, uint32_t plane, size_t i, const fp& a) {
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        base[(size_t)(plane * 3 + q) * stride + i] = make_uint4(a.l[4 * q], a.l[4 * q + 1], a.l[4 * q + 2], a.l[4 * q + 3]);
+}
+__device__ __forceinline__ fp2 soa_ld2(const uint4* base, size_t stride, uint32_t plane, size_t i) {
+    return fp2{soa_ld(base, stride, plane, i), soa_ld(base, stride, plane + 1, i)};
+}
+__device__ __forceinline__ void soa_st2(uint4* base, size_t stride, uint32_t plane, size_t i, const fp2& a) {
+    soa_st(base, stride, plane, i, a.c0);
+    soa_st(base, stride, plane + 1, i, a.c1);
+}
+__device__ __forceinline__ g2_jac soa_ld_g2(const uint4* base, size_t stride, size_t i) {
+    return g2_jac{soa_ld2(base, stride, 0, i), soa_ld2(base, stride, 2, i), soa_ld2(base, stride, 4, i)};
+}
+__device__ __forceinline__ void soa_st_g2(uint4* base, size_t stride, size_t i, const g2_jac& a) {
+    soa_st2(base, stride, 0, i, a.x);
+    soa_st2(base, stride, 2, i, a.y);
+    soa_st2(base, stride, 4, i, a.z);
+}
+__device__ __forceinline__ g1_jac soa_ld_g1(const uint4* base, size_t stride, size_t i) {
+    return g1_jac{soa_ld(base, stride, 0, i), soa_ld(base, stride, 1, i), soa_ld(base, stride, 2, i)};
+}
+__device__ __forceinline__ void soa_st_g1(uint4* base, size_t stride, size_t i, const g1_jac& a) {
+    soa_st(base, stride, 0, i, a.x);
+    soa_st(base, stride, 1, i, a.y);
+    soa_st(base, stride, 2, i, a.z);
+}
+
+// aligned word loads of the reference's AoS records (u64-limb structs: 8-byte aligned)
+__device__ __forceinline__ fp ld_fp_words(const uint32_t* w) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = w[i];
+    return r;
+}
+__device__ __forceinline__ void st_fp_words(uint32_t* w, const fp& a) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = a.l[i];
+}
+__device__ __forceinline__ void st_fp12_words(uint32_t* w, const fp12& a) {
+    const fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        st_fp_words(w + 24 * i, c[i]->c0);
+        st_fp_words(w + 24 * i + 12, c[i]->c1);
+    }
+}
+__device__ __forceinline__ fp12 ld_fp12_words(const uint32_t* w) {
+    fp12 a;
+    fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        c[i]->c0 = ld_fp_words(w + 24 * i);
+        c[i]->c1 = ld_fp_words(w + 24 * i + 12);
+    }
+    return a;
+}
+
+// wave-level exchange of whole structs through DPP/bpermute shuffles
+template <class T>
+__device__ __forceinline__ T shfl_down_struct(const T& v, int delta) {
+    static_assert(sizeof(T) % 4 == 0, "");
+    T r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) d[i] = __shfl_down(s[i], delta, WAVE);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blind: chunk c of B (parallel_chunks.nim:42-66) -> seed = SHA256(rnd || LE64(c)), then per tuple
+// seed <- SHA256(seed) until low u64 != 0 (blst_min_pubkey_sig_core.nim:497-507,:545-556).
+// serial != 0: one chain seeded SHA256(rnd) (batchVerifySerial, core :502-505).
+// Tuples are addressed relative to tuple_base (first tuple of this shard).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd, uint64_t n_total, uint32_t nchunks, uint32_t chunk_lo,
+                                                uint32_t chunk_cnt, uint64_t tuple_base, int serial, uint64_t* __restrict__ r_out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= chunk_cnt) return;
+    uint64_t c = (uint64_t)chunk_lo + t;
+    uint64_t off, len;
+    if (serial) {
+        off = 0;
+        len = n_total;
+    } else {
+        uint64_t base = n_total / nchunks, rem = n_total % nchunks;
+        if (c < rem) {
+            off = (base + 1) * c;
+            len = base + 1;
+        } else {
+            off = base * c + rem;
+            len = base;
+        }
+    }
+    sha256_ctx ctx;
+    sha256_begin(ctx);
+    for (int i = 0; i < 32; i++) sha256_put(ctx, rnd[i]);
+    if (!serial)
+        for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
+    uint32_t seed[8];
+    sha256_end(ctx, seed);
+    for (uint64_t j = 0; j < len; j++) {
+        uint64_t r;
+        do {
+            uint32_t nx[8];
+            sha256_of_digest(seed, nx);
+#pragma unroll
+            for (int i = 0; i < 8; i++) seed[i] = nx[i];
+            r = digest_low_u64_le(seed);
+        } while (r == 0);
+        r_out[off + j - tuple_base] = r;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_hash(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ H, size_t stride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t msg[32];
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t w = mw[j];
+        msg[4 * j] = (uint8_t)w;
+        msg[4 * j + 1] = (uint8_t)(w >> 8);
+        msg[4 * j + 2] = (uint8_t)(w >> 16);
+        msg[4 * j + 3] = (uint8_t)(w >> 24);
+    }
+    g2_jac h = hash_to_g2(msg, 32, dst.b, dst.len);
+    soa_st_g2(H, stride, i, h);
+}
+
+// arbitrary-length message (fastAggregateVerify / coreVerify shape), one lane
+__global__ void k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g2_jac h = hash_to_g2(msg, len, dst.b, dst.len);
+    soa_st_g2(H, stride, slot, h);
+}
+
+__global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
+                                                size_t stride, uint32_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
+    g1_aff pk{ld_fp_words(w), ld_fp_words(w + 12)};
+    if (aff_is_inf(pk)) atomicOr(flags, 1u);        // BLST_PK_IS_INFINITY -> update() false
+    g1_jac q = jac_mul_u64(pk, r[i]);
+    soa_st_g1(P, stride, i, q);
+}
+
+__global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint32_t* __restrict__ part) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    g2_jac acc = jac_inf<fp2>();
+    if (i < n) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 128);
+        g2_aff s{fp2{ld_fp_words(w), ld_fp_words(w + 12)}, fp2{ld_fp_words(w + 24), ld_fp_words(w + 36)}};
+        acc = jac_mul_u64(s, r[i]);                 // infinity signature -> infinity (contributes nothing)
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* o = part + (size_t)blockIdx.x * 72;
+        st_fp_words(o, acc.x.c0); st_fp_words(o + 12, acc.x.c1);
+        st_fp_words(o + 24, acc.y.c0); st_fp_words(o + 36, acc.y.c1);
+        st_fp_words(o + 48, acc.z.c0); st_fp_words(o + 60, acc.z.c1);
+    }
+}
+
+__device__ __forceinline__ g2_jac ld_g2_words(const uint32_t* o) {
+    return g2_jac{fp2{ld_fp_words(o), ld_fp_words(o + 12)}, fp2{ld_fp_words(o + 24), ld_fp_words(o + 36)},
+                  fp2{ld_fp_words(o + 48), ld_fp_words(o + 60)}};
+}
+
+// one wave: sum of the partials -> AggrSign; stored as Q of pair `slot` with P = -G1 (affine, Z = 1)
+__global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ part, uint32_t nparts, uint4* __restrict__ H, uint4* __restrict__ P,
+                                                 size_t stride, size_t slot, uint32_t* __restrict__ agg_out) {
+    g2_jac acc = jac_inf<fp2>();
+    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = jac_add(acc, ld_g2_words(part + (size_t)j * 72));
+    for (int d = 32; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        soa_st_g2(H, stride, slot, acc);
+        g1_jac ng{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()};
+        soa_st_g1(P, stride, slot, ng);
+        st_fp_words(agg_out, acc.x.c0); st_fp_words(agg_out + 12, acc.x.c1);
+        st_fp_words(agg_out + 24, acc.y.c0); st_fp_words(agg_out + 36, acc.y.c1);
+        st_fp_words(agg_out + 48, acc.z.c0); st_fp_words(agg_out + 60, acc.z.c1);
+    }
+}
+
+// lines[s] : 6 fp planes (l0.c0,l0.c1,l1.c0,l1.c1,l2.c0,l2.c1), step-major
+__global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t npairs, size_t stride,
+                                                uint4* __restrict__ lines) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    g1_jac p = soa_ld_g1(P, stride, i);
+    g2_jac q = soa_ld_g2(H, stride, i);
+    miller_lines(p, q, [&](int s, const line_t& l) {
+        uint4* b = lines + (size_t)s * 18 * stride;
+        soa_st2(b, stride, 0, i, l.l0);
+        soa_st2(b, stride, 2, i, l.l1);
+        soa_st2(b, stride, 4, i, l.l2);
+    });
+}
+
+// grid (N_LINES, nblk): block b of step s multiplies lines of pairs b*64*m .. (b+1)*64*m
+__global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lines, uint32_t npairs, size_t stride, uint32_t m,
+                                                   uint32_t* __restrict__ part, uint32_t nblk) {
+    uint32_t s = blockIdx.x, b = blockIdx.y;
+    const uint4* base = lines + (size_t)s * 18 * stride;
+    size_t first = (size_t)b * WAVE * m;
+    fp12 f = fp12_one();
+    bool have = false;
+    for (uint32_t j = 0; j < m; j++) {
+        size_t i = first + (size_t)j * WAVE + threadIdx.x;
+        if (i < npairs) {
+            line_t l{soa_ld2(base, stride, 0, i), soa_ld2(base, stride, 2, i), soa_ld2(base, stride, 4, i)};
+            f = have ? fp12_mul_by_line(f, l) : fp12_from_line(l);
+            have = true;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        fp12 o = shfl_down_struct(f, d);
+        f = fp12_mul(f, o);
+    }
+    if (threadIdx.x == 0) st_fp12_words(part + ((size_t)s * nblk + b) * 144, f);
+}
+
+__global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__ part, uint32_t nblk, uint32_t* __restrict__ L) {
+    uint32_t s = blockIdx.x;
+    fp12 f = fp12_one();
+    for (uint32_t j = threadIdx.x; j < nblk; j += WAVE) {
+        fp12 o = ld_fp12_words(part + ((size_t)s * nblk + j) * 144);
+        f = fp12_mul(f, o);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        fp12 o = shfl_down_struct(f, d);
+        f = fp12_mul(f, o);
+    }
+    if (threadIdx.x == 0) st_fp12_words(L + (size_t)s * 144, f);
+}
+
+// single lane: Horner + conjugate -> miller value
+__global__ void k_combine(const uint32_t* __restrict__ L, uint32_t* __restrict__ miller_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fp12 f = miller_combine([&](int s) { return ld_fp12_words(L + (size_t)s * 144); });
+    st_fp12_words(miller_out, f);
+}
+
+// single lane: product of k committed states, final exponentiation, == 1
+__global__ void k_finalverify(const uint32_t* __restrict__ states, uint32_t kk, uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fp12 f = ld_fp12_words(states);
+    for (uint32_t i = 1; i < kk; i++) f = fp12_mul(f, ld_fp12_words(states + (size_t)i * 144));
+    fp12 g = final_exp(f);
+    st_fp12_words(gt_out, g);
+    *verdict = fp12_is_one(g) ? 1u : 0u;
+}
+
+// Jacobian SoA -> AoS copies for stage inspection
+__global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g2_jac a = soa_ld_g2(H, stride, i);
+    uint32_t* o = out + (size_t)i * 72;
+    st_fp_words(o, a.x.c0); st_fp_words(o + 12, a.x.c1);
+    st_fp_words(o + 24, a.y.c0); st_fp_words(o + 36, a.y.c1);
+    st_fp_words(o + 48, a.z.c0); st_fp_words(o + 60, a.z.c1);
+}
+__global__ void k_export_g1(const uint4* __restrict__ P, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1_jac a = soa_ld_g1(P, stride, i);
+    uint32_t* o = out + (size_t)i * 36;
+    st_fp_words(o, a.x); st_fp_words(o + 12, a.y); st_fp_words(o + 24, a.z);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Context
+// ------------------------------------------------------------------------------------------
+struct mi355_bls_ctx {
+    int device = 0;
+    size_t cap = 0;          // max sets
+    size_t stride = 0;       // pairs capacity (cap + 1 rounded up to 64)
+    uint32_t num_threads = 4096;
+    uint32_t nblk_cap = 64;
+    // device buffers
+    uint8_t* d_sets = nullptr;       // staging for host-pointer calls
+    uint8_t* d_rnd = nullptr;
+    uint64_t* d_r = nullptr;
+    uint4* d_H = nullptr;
+    uint4* d_P = nullptr;
+    uint4* d_lines = nullptr;
+    uint32_t* d_spart = nullptr;
+    uint32_t* d_agg = nullptr;
+    uint32_t* d_lpart = nullptr;
+    uint32_t* d_L = nullptr;
+    uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
+    uint32_t* d_gt = nullptr;
+    uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
+    uint32_t* d_export = nullptr;
+    hipEvent_t ev[9] = {};
+    size_t last_n = 0;
+    bool have_gt = false;
+    float timings[8] = {};
+    dst_t dst;
+};
+
+static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
+
+extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
+
+extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets) {
+    if (!out || max_sets == 0 || max_sets > (1u << 30)) return MI355_BLS_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        g_err = "no such HIP device";
+        return MI355_BLS_ERR_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    auto* c = new mi355_bls_ctx();
+    c->device = device;
+    c->cap = max_sets;
+    c->stride = ((max_sets + 1 + 63) / 64) * 64;
+    std::memset(&c->dst, 0, sizeof(c->dst));
+    c->dst.len = sizeof(DST_SIG) - 1;
+    std::memcpy(c->dst.b, DST_SIG, c->dst.len);
+    size_t nwaves = c->stride / 64;
+#define ALLOC(p, bytes)                                   \
+    do {                                                  \
+        hipError_t e_ = hipMalloc((void**)&(p), (bytes)); \
+        if (e_ != hipSuccess) {                           \
+            g_err = std::string("hipMalloc " #p ": ") + hipGetErrorString(e_); \
+            mi355_bls_ctx_destroy(c);                     \
+            return MI355_BLS_ERR_HIP;                     \
+        }                                                 \
+    } while (0)
+    ALLOC(c->d_sets, max_sets * 320);
+    ALLOC(c->d_rnd, 32);
+    ALLOC(c->d_r, c->stride * 8);
+    ALLOC(c->d_H, c->stride * 288);
+    ALLOC(c->d_P, c->stride * 144);
+    ALLOC(c->d_lines, c->stride * 288 * (size_t)N_LINES);
+    ALLOC(c->d_spart, nwaves * 288);
+    ALLOC(c->d_agg, 288);
+    ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * 576);
+    ALLOC(c->d_L, (size_t)N_LINES * 576);
+    ALLOC(c->d_states, 64 * 576);
+    ALLOC(c->d_gt, 576);
+    ALLOC(c->d_flags, 16);
+    ALLOC(c->d_export, c->stride * 288);
+#undef ALLOC
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    *out = c;
+    return 0;
+}
+
+extern "C" int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* c, uint32_t nt) {
+    if (!c || nt == 0) return MI355_BLS_ERR_ARG;
+    c->num_threads = nt;
+    return 0;
+}
+
+extern "C" void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t lo, uint32_t hi, size_t* first, size_t* count) {
+    size_t B = n_total < num_threads ? n_total : num_threads;
+    if (B == 0 || lo >= hi) {
+        *first = 0;
+        *count = 0;
+        return;
+    }
+    if (hi > B) hi = (uint32_t)B;
+    size_t base = n_total / B, rem = n_total % B;
+    auto off = [&](size_t c) { return c < rem ? (base + 1) * c : base * c + rem; };
+    *first = off(lo);
+    *count = off(hi) - off(lo);      // off(B) == n_total
+}
+
+// Enqueues everything up to the shard's committed state (d_states slot 0).  n = local tuple count.
+static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
+                     size_t tuple_base, size_t n, int serial, const uint8_t rnd[32], hipStream_t st) {
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_rnd, rnd, 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    uint32_t n32 = (uint32_t)n, npairs = n32 + 1;
+    uint32_t nb = (n32 + WAVE - 1) / WAVE;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, serial, c->d_r);
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    k_hash<<<nb, WAVE, 0, st>>>(d_sets, n32, c->dst, c->d_H, c->stride);
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_spart);
+    k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    k_lines<<<(npairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, npairs, c->stride, c->d_lines);
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    uint32_t nblk = 32;
+    uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
+    if (m < 1) m = 1;
+    nblk = (npairs + WAVE * m - 1) / (WAVE * m);
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk);
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_L);
+    HIPCHK(hipEventRecord(c->ev[6], st));
+    k_combine<<<1, 1, 0, st>>>(c->d_L, c->d_states);
+    HIPCHK(hipEventRecord(c->ev[7], st));
+    HIPCHK(hipGetLastError());
+    c->last_n = n;
+    c->have_gt = false;
+    return 0;
+}
+
+static int collect_timings(mi355_bls_ctx* c, int last_ev) {
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    for (int i = 0; i < last_ev; i++) HIPCHK(hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&c->timings[7], c->ev[0], c->ev[last_ev]));
+    return 0;
+}
+
+static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
+    if (!c || !rnd) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                      // bls_batch_verifier.nim:137-139, :312-314
+    if (!d_sets) return MI355_BLS_ERR_ARG;
+    uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
+    int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
+    if (rc) return rc;
+    k_finalverify<<<1, 1, 0, st>>>(c->d_states, 1, c->d_gt, c->d_flags + 1);
+    HIPCHK(hipEventRecord(c->ev[8], st));
+    uint32_t fl[2];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->have_gt = true;
+    float fin = 0;
+    rc = collect_timings(c, 7);
+    if (rc) return rc;
+    HIPCHK(hipEventElapsedTime(&fin, c->ev[7], c->ev[8]));
+    c->timings[6] += fin;
+    c->timings[7] += fin;
+    return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
+}
+
+extern "C" int mi355_bls_batch_verify_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream) {
+    return verify_common(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);
+}
+
+static int verify_host(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32], int serial) {
+    if (!c || !rnd) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!sets) return MI355_BLS_ERR_ARG;
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_sets, sets, n * 320, hipMemcpyHostToDevice, nullptr));
+    return verify_common(c, c->d_sets, n, rnd, serial, nullptr);
+}
+
+extern "C" int mi355_bls_batch_verify(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 0); }
+extern "C" int mi355_bls_batch_verify_serial(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 1); }
+
+extern "C" int mi355_bls_batch_shard_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
+                                            const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok) {
+    if (!c || !rnd || !out_fp12 || !out_ok || n_total == 0) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t B = (uint32_t)(n_total < c->num_threads ? n_total : c->num_threads);
+    if (chunk_hi > B) chunk_hi = B;
+    if (chunk_lo >= chunk_hi) return MI355_BLS_ERR_ARG;
+    size_t first, count;
+    mi355_bls_chunk_range(n_total, c->num_threads, chunk_lo, chunk_hi, &first, &count);
+    int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
+    if (rc) return rc;
+    uint32_t fl = 0;
+    HIPCHK(hipMemcpyAsync(out_fp12, c->d_states, 576, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&fl, c->d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *out_ok = fl == 0 ? 1 : 0;
+    return collect_timings(c, 7);
+}
+
+extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp12s, size_t kk) {
+    if (!c || !fp12s || kk == 0 || kk > 64) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_states, fp12s, kk * 576, hipMemcpyHostToDevice, nullptr));
+    k_finalverify<<<1, 1, 0, nullptr>>>(c->d_states, (uint32_t)kk, c->d_gt, c->d_flags + 1);
+    uint32_t v = 0;
+    HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    c->have_gt = true;
+    return v == 1 ? 1 : 0;
+}
+
+extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size_t out_bytes) {
+    if (!c || !out) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    size_t n = c->last_n;
+    uint32_t nb = (uint32_t)((n + 63) / 64);
+    switch (what) {
+        case 0:
+            if (out_bytes < n * 8) return MI355_BLS_ERR_ARG;
+            HIPCHK(hipMemcpy(out, c->d_r, n * 8, hipMemcpyDeviceToHost));
+            return 0;
+        case 1:
+            if (out_bytes < n * 288 || n == 0) return MI355_BLS_ERR_ARG;
+            k_export_g2<<<nb, 64>>>(c->d_H, c->stride, (uint32_t)n, c->d_export);
+            HIPCHK(hipMemcpy(out, c->d_export, n * 288, hipMemcpyDeviceToHost));
+            return 0;
+        case 2:
+            if (out_bytes < n * 144 || n == 0) return MI355_BLS_ERR_ARG;
+            k_export_g1<<<nb, 64>>>(c->d_P, c->stride, (uint32_t)n, c->d_export);
+            HIPCHK(hipMemcpy(out, c->d_export, n * 144, hipMemcpyDeviceToHost));
+            return 0;
+        case 3:
+            if (out_bytes < 288) return MI355_BLS_ERR_ARG;
+            HIPCHK(hipMemcpy(out, c->d_agg, 288, hipMemcpyDeviceToHost));
+            return 0;
+        case 4:
+            if (out_bytes < 576 || !c->have_gt) return MI355_BLS_ERR_ARG;
+            HIPCHK(hipMemcpy(out, c->d_gt, 576, hipMemcpyDeviceToHost));
+            return 0;
+        case 5:
+            if (out_bytes < 576) return MI355_BLS_ERR_ARG;
+            HIPCHK(hipMemcpy(out, c->d_states, 576, hipMemcpyDeviceToHost));
+            return 0;
+    }
+    return MI355_BLS_ERR_ARG;
+}
+
+extern "C" int mi355_bls_last_timings(mi355_bls_ctx* c, float out[8]) {
+    if (!c || !out) return MI355_BLS_ERR_ARG;
+    for (int i = 0; i < 8; i++) out[i] = c->timings[i];
+    return 0;
+}
