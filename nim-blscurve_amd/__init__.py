@@ -35,6 +35,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise BlsGpuError("HIP extension missing: %s (run nim-blscurve_amd/build.sh); no CPU fallback exists" % LIB_PATH)
+        # torch bundles its own HIP runtime with the same soname as /opt/rocm's: whichever loads first
+        # serves both, and torch must be that one or it later reports "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
         L.mi355_bls_ctx_create.argtypes = [ctypes.POINTER(vp), i32, sz]

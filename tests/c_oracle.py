@@ -1,0 +1,86 @@
+"""ctypes binding of oracle/_build/libbls_oracle.so (the C restatement; checker only)."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libbls_oracle.so"))
+        vp, sz, i32, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p
+        L.oracle_batch_verify.argtypes = [cp, sz, cp, i32, vp, vp, vp, vp, vp]
+        L.oracle_hash_to_g2.argtypes = [cp, sz, cp, sz, cp]
+        L.oracle_sk_to_pk.argtypes = [cp, cp]
+        L.oracle_sign.argtypes = [cp, cp, sz, cp]
+        L.oracle_g2_mul.argtypes = [cp, cp, cp]
+        L.oracle_make_batch.argtypes = [vp, sz, ctypes.c_uint64]
+        L.oracle_g1_sum.argtypes = [cp, sz, cp]
+        L.oracle_fast_aggregate_verify.argtypes = [cp, sz, cp, sz, cp]
+        L.oracle_msm_g1.argtypes = [cp, cp, sz, i32, cp]
+        L.oracle_sha256.argtypes = [cp, sz, cp]
+        _lib = L
+    return _lib
+
+
+def batch_verify(sets, rnd, nthreads, stages=False):
+    n = len(sets) // 320
+    if not stages:
+        return bool(lib().oracle_batch_verify(sets, n, rnd, nthreads, None, None, None, None, None))
+    r = (ctypes.c_uint64 * max(n, 1))()
+    h = ctypes.create_string_buffer(192 * max(n, 1))
+    p = ctypes.create_string_buffer(96 * max(n, 1))
+    a = ctypes.create_string_buffer(192)
+    g = ctypes.create_string_buffer(576)
+    ok = bool(lib().oracle_batch_verify(sets, n, rnd, nthreads, r, h, p, a, g))
+    return ok, {"r": list(r)[:n], "H": h.raw, "rPK": p.raw, "aggsig": a.raw, "gt": g.raw}
+
+
+def make_batch(n, seed=0):
+    b = ctypes.create_string_buffer(320 * n)
+    lib().oracle_make_batch(b, n, seed)
+    return b.raw
+
+
+def hash_to_g2(msg, dst):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_hash_to_g2(msg, len(msg), dst, len(dst), o)
+    return o.raw
+
+
+def sk_to_pk(sk_int):
+    o = ctypes.create_string_buffer(96)
+    lib().oracle_sk_to_pk(sk_int.to_bytes(32, "little"), o)
+    return o.raw
+
+
+def sign(sk_int, msg):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_sign(sk_int.to_bytes(32, "little"), msg, len(msg), o)
+    return o.raw
+
+
+def g2_mul(p192, k_int):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_g2_mul(p192, k_int.to_bytes(32, "little"), o)
+    return o.raw
+
+
+def g1_sum(pts):
+    o = ctypes.create_string_buffer(96)
+    lib().oracle_g1_sum(pts, len(pts) // 96, o)
+    return o.raw
+
+
+def fast_aggregate_verify(pks, msg, sig):
+    return bool(lib().oracle_fast_aggregate_verify(pks, len(pks) // 96, msg, len(msg), sig))
+
+
+def msm_g1(pts, scalars, nbits=255):
+    o = ctypes.create_string_buffer(96)
+    lib().oracle_msm_g1(pts, scalars, len(pts) // 96, nbits, o)
+    return o.raw

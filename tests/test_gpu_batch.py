@@ -117,3 +117,31 @@ def test_large_batch_properties(m):
     assert m.batchVerify(cache, bytes(bad), rnd) is False
     rev = b"".join(recs[(n - 1 - i) % 17] for i in range(n))
     assert m.batchVerify(cache, rev, rnd) is True
+
+
+@pytest.mark.parametrize("n,nt", [(1000, 4096), (257, 7), (4096, 4096)])
+def test_parity_vs_c_oracle_at_scale(m, n, nt):
+    """Distinct random valid tuples (C restatement as generator + checker): every r_i, H(m_i),
+    [r_i]PK_i, the aggregated signature and the final GT value are bit-exact after canonicalisation."""
+    import c_oracle as co
+    rec = co.make_batch(n, seed=77)
+    rnd = o.sha256(b"Mr F was here")
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nt)
+    assert m.batchVerifyParallel(cache, rec, rnd) is True
+    ok, st = co.batch_verify(rec, rnd, nt, stages=True)
+    assert ok
+    r = struct.unpack("<%dQ" % n, cache.fetch(0, 8 * n))
+    assert list(r) == st["r"]
+    H = cache.fetch(1, 288 * n)
+    P = cache.fetch(2, 144 * n)
+    step = max(1, n // 64)          # canonicalising needs a python inversion per point: sample
+    for i in list(range(0, n, step)) + [n - 1]:
+        assert o.g2_to_blst_affine(g2_jac_to_affine(H[288 * i:288 * i + 288])) == st["H"][192 * i:192 * i + 192]
+        assert o.g1_to_blst_affine(g1_jac_to_affine(P[144 * i:144 * i + 144])) == st["rPK"][96 * i:96 * i + 96]
+    assert o.g2_to_blst_affine(g2_jac_to_affine(cache.fetch(3, 288))) == st["aggsig"]
+    assert cache.fetch(4, 576) == st["gt"]
+    # one corrupted signature (still a curve point: swap two signatures) -> false on both
+    bad = bytearray(rec)
+    bad[128:320], bad[320 + 128:640] = rec[320 + 128:640], rec[128:320]
+    assert m.batchVerifyParallel(cache, bytes(bad), rnd) is False
+    assert co.batch_verify(bytes(bad), rnd, nt) is False
