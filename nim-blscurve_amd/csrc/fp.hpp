@@ -120,8 +120,30 @@ BLS_HD fp fp_neg(const fp& a) {
 
 BLS_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p (CIOS, 32-bit limbs; top word of p < 2^31 so 13 words suffice).
-BLS_HDN fp fp_mul(const fp& a, const fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fp_mul_gfx950.inc"
+// The multiplier body (~770 instructions, ~5.5 KB) is shared by every caller so that hot loops fit the
+// 64 KB instruction cache.  Operands travel in VGPRs: 24 scalar parameters map to v0..v23 and the
+// result returns in v0..v11 (aggregate by-reference parameters would go through scratch memory,
+// which at 65 536 lanes no longer fits L2).
+__device__ __noinline__ fp fp_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                       uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                       uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
+    fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11}};
+    return fp_mul_gfx950(a, b);
+}
+#endif
+
+// Montgomery product a*b*R^-1 mod p.  Device: product-scanning columns of v_mad_u64_u32 +
+// v_addc_co_u32 pairs (fp_mul_gfx950.inc).  Host (tests/host_emu only): portable CIOS with 32-bit
+// limbs; top word of p < 2^31 so 13 words suffice.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
+    return fp_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
+                       b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+}
+#else
+__host__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
     uint32_t t[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) t[i] = 0;
@@ -154,6 +176,7 @@ BLS_HDN fp fp_mul(const fp& a, const fp& b) {
     for (int i = 0; i < 12; i++) lo[i] = t[i];
     return fp_reduce_once(lo, t[12]);
 }
+#endif
 
 BLS_HD fp fp_sqr(const fp& a) { return fp_mul(a, a); }
 
