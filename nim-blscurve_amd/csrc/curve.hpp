@@ -70,7 +70,7 @@ BLS_HD jac<F> jac_select(bool c, const jac<F>& a, const jac<F>& b) {
 
 // dbl-2009-l (a = 0): 2M + 5S.  Z = 0 or Y = 0 give Z3 = 0.
 template <class F>
-BLS_HDN jac<F> jac_dbl(const jac<F>& p) {
+BLS_MID jac<F> jac_dbl(const jac<F>& p) {
     F A = f_sqr(p.x);
     F B = f_sqr(p.y);
     F C = f_sqr(B);
@@ -88,7 +88,7 @@ BLS_HDN jac<F> jac_dbl(const jac<F>& p) {
 
 // Jacobian + affine, complete (handles infinity operands, P == Q, P == -Q).
 template <class F>
-BLS_HDN jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
+BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     bool p_inf = jac_is_inf(p);
     bool q_inf = aff_is_inf(q);
     F Z1Z1 = f_sqr(p.z);

@@ -15,6 +15,13 @@
 
 #define BLS_HD __host__ __device__ __forceinline__
 #define BLS_HDN __host__ __device__ __noinline__
+// Mid-level formulas: inlined on the device so operands stay in VGPRs/AGPRs between the register-argument
+// calls into the shared multiplier body; kept out-of-line on the host to keep tests/host_emu quick to build.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BLS_MID __device__ __forceinline__
+#else
+#define BLS_MID __host__ __device__ __noinline__
+#endif
 #define BLS_CONST static constexpr
 #include "constants.hpp"
 

@@ -58,7 +58,7 @@ BLS_HDN void hash_to_field_fp2x2(fp2& u0, fp2& u1, const uint8_t* msg, uint32_t 
 
 // (is_square(N/D), y) with y = sqrt(N/D) if square, else sqrt(Z * N/D); Z = -(2+u), norm(Z) = 5.
 // Two Fp exponentiations; the first also yields 1/norm(D).
-BLS_HDN bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
+BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
     fp nN = fp2_norm(N), nD = fp2_norm(D);
     fp M = fp_mul(nN, nD);
     fp t = fp_recip_sqrt_pow(M);
@@ -86,7 +86,7 @@ BLS_HDN bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
 }
 
 // Simplified SWU onto E2': y^2 = x^3 + 240u x + 1012(1+u)  (RFC 9380 appendix F.2), Jacobian output.
-BLS_HDN g2_jac sswu_g2(const fp2& u) {
+BLS_MID g2_jac sswu_g2(const fp2& u) {
     const fp2 A = fp2_from_const(k::SSWU_A), B = fp2_from_const(k::SSWU_B), Z = fp2_from_const(k::SSWU_Z);
     fp2 tv1 = fp2_mul(Z, fp2_sqr(u));
     fp2 tv2 = fp2_add(fp2_sqr(tv1), tv1);
@@ -107,7 +107,7 @@ BLS_HDN g2_jac sswu_g2(const fp2& u) {
 }
 
 // 3-isogeny E2' -> E2 on Jacobian coordinates: (XN(X,Z^2), Y*YN(X,Z^2), Z*(X - xK Z^2))
-BLS_HDN g2_jac iso3_g2(const g2_jac& p) {
+BLS_MID g2_jac iso3_g2(const g2_jac& p) {
     fp2 z2 = fp2_sqr(p.z), z4 = fp2_sqr(z2), z6 = fp2_mul(z4, z2);
     fp2 xn = fp2_add(fp2_mul(fp2_from_const(k::ISO_XN3), p.x), fp2_mul(fp2_from_const(k::ISO_XN2), z2));
     xn = fp2_add(fp2_mul(xn, p.x), fp2_mul(fp2_from_const(k::ISO_XN1), z4));
@@ -142,9 +142,12 @@ BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
 BLS_HDN g2_jac hash_to_g2(const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
     fp2 u0, u1;
     hash_to_field_fp2x2(u0, u1, msg, msg_len, dst, dst_len);
-    g2_jac q0 = iso3_g2(sswu_g2(u0));
-    g2_jac q1 = iso3_g2(sswu_g2(u1));
-    return clear_cofactor_g2(jac_add(q0, q1));
+    // one copy of the (inlined) map code, executed for u0 then u1
+    fp2 u[2] = {u0, u1};
+    g2_jac q[2];
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < 2; j++) q[j] = iso3_g2(sswu_g2(u[j]));
+    return clear_cofactor_g2(jac_add(q[0], q[1]));
 }
 
 }  // namespace bls

@@ -36,7 +36,7 @@ BLS_HD line_t line_scale(const fp2& c0, const fp2& c1, const fp2& c2, const g1_p
 BLS_HD line_t line_one() { return line_t{fp2_one(), fp2_zero(), fp2_zero()}; }
 
 // T <- 2T, returns tangent line at T evaluated at P.
-BLS_HDN line_t miller_dbl_step(g2_jac& t, const g1_pre& p) {
+BLS_MID line_t miller_dbl_step(g2_jac& t, const g1_pre& p) {
     fp2 A = fp2_sqr(t.x);
     fp2 B = fp2_sqr(t.y);
     fp2 C = fp2_sqr(B);
@@ -61,7 +61,7 @@ struct g2_addpre {
 };
 
 // T <- T + Q, returns chord line through T and Q evaluated at P.
-BLS_HDN line_t miller_add_step(g2_jac& t, const g2_jac& q, const g2_addpre& qp, const g1_pre& p) {
+BLS_MID line_t miller_add_step(g2_jac& t, const g2_jac& q, const g2_addpre& qp, const g1_pre& p) {
     fp2 Z1Z1 = fp2_sqr(t.z);
     fp2 U1 = fp2_mul(t.x, qp.z2);
     fp2 U2 = fp2_mul(q.x, Z1Z1);

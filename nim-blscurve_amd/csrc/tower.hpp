@@ -34,7 +34,7 @@ BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
 }
 
 // a * (l0 + l1 v): 5 fp2 multiplications
-BLS_HDN fp6 fp6_mul_by_01(const fp6& a, const fp2& l0, const fp2& l1) {
+BLS_MID fp6 fp6_mul_by_01(const fp6& a, const fp2& l0, const fp2& l1) {
     fp2 t0 = fp2_mul(a.a0, l0);
     fp2 t1 = fp2_mul(a.a1, l1);
     fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.a0, a.a1), fp2_add(l0, l1)), t0), t1);
@@ -88,7 +88,7 @@ struct line_t {
 };
 
 // f * line: 13 fp2 multiplications
-BLS_HDN fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
+BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     fp6 t0 = fp6_mul_by_01(f.c0, l.l0, l.l1);
     fp6 t1 = fp6_mul_by_1(f.c1, l.l2);
     fp6 s = fp6_mul_by_01(fp6_add(f.c0, f.c1), l.l0, fp2_add(l.l1, l.l2));
