@@ -69,23 +69,25 @@ def main():
     nthreads = cache.numThreads * world                     # global number of blinding chains
     if world > 1:
         m._check(m.lib().mi355_bls_ctx_set_num_threads(cache._h, nthreads))
-    per_rank = nthreads // world
     stream = torch.cuda.current_stream().cuda_stream
+
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nim_blscurve_amd.sharded", os.path.join(ROOT, "nim-blscurve_amd", "sharded.py"))
+    sharded = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharded)
+
+    def all_gather(blob):
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        allst = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allst, mine)               # RCCL; 584 B per rank
+        return [bytes(t.cpu().numpy().tobytes()) for t in allst]
 
     def step(it):
         r = bytes(rnd)
         if world == 1:
-            ok = cache.verify_device(d_sets.data_ptr(), n, r, stream)
-        else:
-            st, okf = cache.shard_device(d_sets.data_ptr(), n_total, rank * per_rank, (rank + 1) * per_rank, r, stream)
-            mine = torch.frombuffer(bytearray(st + bytes([1 if okf else 0]) + bytes(7)), dtype=torch.uint8).to(dev)
-            allst = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allst, mine)
-            ok = True
-            if rank == 0:
-                blobs = [bytes(t.cpu().numpy().tobytes()) for t in allst]
-                ok = all(b[576] == 1 for b in blobs) and cache.finalverify_shards([b[:576] for b in blobs])
-        return ok
+            return cache.verify_device(d_sets.data_ptr(), n, r, stream)
+        v = sharded.batch_verify_sharded(cache, d_sets.data_ptr(), n_total, rank, world, r, all_gather, stream)
+        return True if v is None else v
 
     def sync():
         if world > 1:
