@@ -80,6 +80,20 @@ int mi355_bls_finalverify_shards(mi355_bls_ctx* ctx, const uint8_t* fp12s, size_
  * n_total sets split into num_threads chunks (parallel_chunks.nim:42-66). */
 void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t chunk_lo, uint32_t chunk_hi, size_t* first, size_t* count);
 
+/* aggregateAll on G1 (blst_min_pubkey_sig_core.nim:179-195: blst_p1_from_affine + a serial loop of
+ * blst_p1_add_or_double_affine): sum of n blst_p1_affine points -> blst_p1 (Jacobian, 144 B; the
+ * caller finishes with blst_p1_to_affine as the reference's `finish` does).  Host or device input. */
+int mi355_bls_g1_aggregate(mi355_bls_ctx* ctx, const void* pks, size_t n, uint8_t out_p1[144]);
+int mi355_bls_g1_aggregate_device(mi355_bls_ctx* ctx, const void* d_pks, size_t n, void* stream, uint8_t out_p1[144]);
+
+/* fastAggregateVerify(publicKeys, message, signature) (bls_sig_min_pubkey.nim:234-258): aggregate the
+ * n public keys on the device, then coreVerifyNoGroupCheck (core :269-297): e(agg, H(msg)) == e(G1, sig).
+ * pks: n x 96 B blst_p1_affine, sig: 192 B blst_p2_affine (host memory), msg_len <= 4096.
+ * n == 0 -> 0; aggregate at infinity -> 0. */
+int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, size_t n, const uint8_t* msg, size_t msg_len, const void* sig);
+int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* ctx, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
+                                           const void* sig, void* stream);
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

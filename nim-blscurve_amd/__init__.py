@@ -55,6 +55,10 @@ def lib():
         L.mi355_bls_finalverify_shards.argtypes = [vp, ctypes.c_char_p, sz]
         L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mi355_bls_chunk_range.restype = None
+        L.mi355_bls_g1_aggregate.argtypes = [vp, vp, sz, ctypes.c_char_p]
+        L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
+        L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
+        L.mi355_bls_fast_aggregate_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p, vp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
@@ -171,3 +175,28 @@ def batchVerify(cache, input_, secureRandomBytes):
     if cache.numThreads > 1 and n >= 3:
         return batchVerifyParallel(cache, rec, secureRandomBytes)
     return batchVerifySerial(cache, rec, secureRandomBytes)
+
+
+def aggregateAll(cache, publicKeys):
+    """G1 aggregateAll (blst_min_pubkey_sig_core.nim:179-195): n x 96-byte affine keys -> 144-byte blst_p1.
+    Empty input -> None (the reference returns false)."""
+    buf = bytes(publicKeys) if isinstance(publicKeys, (bytes, bytearray, memoryview)) else b"".join(publicKeys)
+    if len(buf) % 96:
+        raise ValueError("public keys are 96-byte blst_p1_affine images")
+    n = len(buf) // 96
+    if n == 0:
+        return None
+    out = ctypes.create_string_buffer(144)
+    _check(lib().mi355_bls_g1_aggregate(cache._h, buf, n, out))
+    return out.raw
+
+
+def fastAggregateVerify(cache, publicKeys, message, signature):
+    """bls_sig_min_pubkey.nim:234-258.  Empty key list -> False."""
+    buf = bytes(publicKeys) if isinstance(publicKeys, (bytes, bytearray, memoryview)) else b"".join(publicKeys)
+    if len(buf) % 96 or len(signature) != 192:
+        raise ValueError("public keys are 96-byte, the signature a 192-byte BLST affine image")
+    n = len(buf) // 96
+    if n == 0:
+        return False
+    return bool(_check(lib().mi355_bls_fast_aggregate_verify(cache._h, buf, n, bytes(message), len(message), bytes(signature))))

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
                                                     uint32_t xpair, uint32_t* __restrict__ L) {
     uint32_t s = blockIdx.x;
     fp12 f = fp12_one();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && xpair != 0xffffffffu) {
         const uint4* base = lines + (size_t)s * 18 * stride;
         f = fp12_from_line(line_t{soa_ld2(base, stride, 0, xpair), soa_ld2(base, stride, 2, xpair), soa_ld2(base, stride, 4, xpair)});
     }
@@ -485,6 +485,57 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// G1 point-sum reduction (aggregateAll, blst_min_pubkey_sig_core.nim:179-195; the streaming part
+// of fastAggregateVerify, bls_sig_min_pubkey.nim:234-258): 96 B in per ~11 Fp multiplications.
+// Lane l of block b sums points (b*64 + l) + j*64*gridDim.x, j < m, with mixed additions, then the
+// wave folds its 64 partial sums with shuffles.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts, uint32_t n, uint32_t m, uint32_t* __restrict__ part) {
+    uint32_t lane0 = blockIdx.x * WAVE + threadIdx.x, strideL = gridDim.x * WAVE;
+    g1_jac acc = jac_inf<fp>();
+    for (uint32_t j = 0; j < m; j++) {
+        uint32_t i = lane0 + j * strideL;
+        if (i < n) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + (size_t)i * 96);
+            g1_aff q{ld_fp_words(w), ld_fp_words(w + 12)};
+            acc = jac_add_aff(acc, q);
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        g1_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* o = part + (size_t)blockIdx.x * 36;
+        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_g1_sum2(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ out) {
+    g1_jac acc = jac_inf<fp>();
+    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) {
+        const uint32_t* o = part + (size_t)j * 36;
+        acc = jac_add(acc, g1_jac{ld_fp_words(o), ld_fp_words(o + 12), ld_fp_words(o + 24)});
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        g1_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) { st_fp_words(out, acc.x); st_fp_words(out + 12, acc.y); st_fp_words(out + 24, acc.z); }
+}
+// pairs of coreVerifyNoGroupCheck (core :269-297): slot 0 = (aggregate pk, H(msg)) [H written by k_hash_one],
+// slot 1 = (-G1, signature).  Aggregate at infinity -> BLST_PK_IS_INFINITY flag.
+__global__ void k_fav_setup(const uint32_t* __restrict__ agg, const uint32_t* __restrict__ sig, uint4* __restrict__ H, uint4* __restrict__ P,
+                            size_t stride, uint32_t* __restrict__ flags) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1_jac a{ld_fp_words(agg), ld_fp_words(agg + 12), ld_fp_words(agg + 24)};
+    if (jac_is_inf(a)) atomicOr(flags, 1u);
+    soa_st_g1(P, stride, 0, a);
+    soa_st_g1(P, stride, 1, g1_jac{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()});
+    g2_aff sg{fp2{ld_fp_words(sig), ld_fp_words(sig + 12)}, fp2{ld_fp_words(sig + 24), ld_fp_words(sig + 36)}};
+    soa_st_g2(H, stride, 1, jac_from_aff(sg));
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,6 +574,8 @@ struct mi355_bls_ctx {
     uint4* d_lines = nullptr;
     uint32_t* d_spart = nullptr;
     uint32_t* d_agg = nullptr;
+    uint32_t* d_agg1 = nullptr;      // G1 aggregate (blst_p1 image)
+    uint8_t* d_msg = nullptr;        // message (<= 4096 B) + signature staging
     uint32_t* d_lpart = nullptr;
     uint32_t* d_L = nullptr;
     uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
@@ -546,7 +599,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_agg1, c->d_msg, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -591,12 +644,14 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_lines, c->stride * 288 * (size_t)N_LINES);
     ALLOC(c->d_spart, nwaves * 288);
     ALLOC(c->d_agg, 288);
+    ALLOC(c->d_agg1, 144);
+    ALLOC(c->d_msg, 4096 + 192);
     ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * 576);
     ALLOC(c->d_L, (size_t)N_LINES * 576);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_flags, 16);
-    ALLOC(c->d_export, c->stride * 288);
+    ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * 144);
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -797,4 +852,88 @@ extern "C" int mi355_bls_last_timings(mi355_bls_ctx* c, float out[8]) {
     if (!c || !out) return MI355_BLS_ERR_ARG;
     for (int i = 0; i < 8; i++) out[i] = c->timings[i];
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// aggregateAll / fastAggregateVerify
+// ------------------------------------------------------------------------------------------
+static int g1_sum_enqueue(mi355_bls_ctx* c, const uint8_t* d_pts, size_t n, hipStream_t st) {
+    // result (blst_p1 image, 144 B) lands in d_agg1
+    uint32_t n32 = (uint32_t)n;
+    uint32_t nblk = (n32 + WAVE * 8 - 1) / (WAVE * 8);          // ~8 points per lane
+    if (nblk > c->slots * 2) nblk = c->slots * 2;
+    if (nblk < 1) nblk = 1;
+    uint32_t m = (n32 + nblk * WAVE - 1) / (nblk * WAVE);
+    k_g1_sum<<<nblk, WAVE, 0, st>>>(d_pts, n32, m, c->d_export);
+    k_g1_sum2<<<1, WAVE, 0, st>>>(c->d_export, nblk, c->d_agg1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi355_bls_g1_aggregate_device(mi355_bls_ctx* c, const void* d_pks, size_t n, void* stream, uint8_t out_p1[144]) {
+    if (!c || !d_pks || !out_p1 || n == 0) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipMemcpyAsync(out_p1, c->d_agg1, 144, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    HIPCHK(hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]));
+    c->timings[7] = c->timings[0];
+    return 0;
+}
+
+extern "C" int mi355_bls_g1_aggregate(mi355_bls_ctx* c, const void* pks, size_t n, uint8_t out_p1[144]) {
+    if (!c || !pks || !out_p1 || n == 0) return MI355_BLS_ERR_ARG;
+    if (n * 96 > c->cap * 320) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_sets, pks, n * 96, hipMemcpyHostToDevice, nullptr));
+    return mi355_bls_g1_aggregate_device(c, c->d_sets, n, nullptr, out_p1);
+}
+
+extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
+                                                      const void* sig, void* stream) {
+    if (!c || !sig || (!msg && msg_len) || msg_len > 4096) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                                     // bls_sig_min_pubkey.nim:251-253
+    if (!d_pks) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipMemcpyAsync(c->d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    k_hash_one<<<1, 1, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
+    k_fav_setup<<<1, 1, 0, st>>>(c->d_agg1, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    k_lines<<<1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, 2, c->stride, c->d_lines);
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    k_lineprod<<<dim3(N_LINES, 1), WAVE, 0, st>>>(c->d_lines, 2, c->stride, 1, c->d_lpart, 1);
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_lines, c->stride, 0xffffffffu, c->d_L);
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1);
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    uint32_t fl[2];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->have_gt = true;
+    c->last_n = 0;
+    rc = collect_timings(c, 5);      // [0] g1 sum, [1] hash+setup, [2] lines, [3] products, [4] tail
+    if (rc) return rc;
+    return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
+}
+
+extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks, size_t n, const uint8_t* msg, size_t msg_len, const void* sig) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!pks) return MI355_BLS_ERR_ARG;
+    if (n * 96 > c->cap * 320) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_sets, pks, n * 96, hipMemcpyHostToDevice, nullptr));
+    return mi355_bls_fast_aggregate_verify_device(c, c->d_sets, n, msg, msg_len, sig, nullptr);
 }

@@ -1,0 +1,69 @@
+"""GPU parity: G1 aggregateAll and fastAggregateVerify (bls_sig_min_pubkey.nim:234-258) through the C ABI."""
+import hashlib
+
+import pytest
+
+import bls12381_py as o
+from util import g1_jac_to_affine, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def cache(m):
+    return m.BatchedBLSVerifierCache.init(max_sets=16384)
+
+
+def test_aggregate_golden(m, cache):
+    a = golden("msm")["aggregate"]
+    pts = bytes.fromhex(a["points"])
+    out = m.aggregateAll(cache, pts)
+    assert o.g1_to_blst_affine(g1_jac_to_affine(out)).hex() == a["sum_affine"]
+    for n in (1, 2, 63, 64, 65, 200):
+        sub = pts[:96 * n]
+        want = o.aggregate_g1([o.g1_from_blst_affine(sub[96 * i:96 * i + 96]) for i in range(n)])
+        assert g1_jac_to_affine(m.aggregateAll(cache, sub)) == want
+    assert m.aggregateAll(cache, b"") is None
+    # P + (-P) + Q = Q ; doubling inside the reduction: P + P
+    p = o.g1_from_blst_affine(pts[:96])
+    q = o.g1_from_blst_affine(pts[96:192])
+    buf = o.g1_to_blst_affine(p) + o.g1_to_blst_affine(o.g1_neg(p)) + o.g1_to_blst_affine(q)
+    assert g1_jac_to_affine(m.aggregateAll(cache, buf)) == q
+    assert g1_jac_to_affine(m.aggregateAll(cache, pts[:96] * 2)) == o.g1_add(p, p)
+    assert g1_jac_to_affine(m.aggregateAll(cache, o.g1_to_blst_affine(p) + o.g1_to_blst_affine(o.g1_neg(p)))) is None
+
+
+def test_fast_aggregate_verify_golden(m, cache):
+    for v in golden("fav"):
+        pks, msg = bytes.fromhex(v["pks"]), bytes.fromhex(v["msg"])
+        assert m.fastAggregateVerify(cache, pks, msg, bytes.fromhex(v["sig"])) is True
+        assert m.fastAggregateVerify(cache, pks, msg, bytes.fromhex(v["bad_sig"])) is False
+        assert m.fastAggregateVerify(cache, pks, msg + b"x", bytes.fromhex(v["sig"])) is False
+    assert m.fastAggregateVerify(cache, b"", b"m", bytes(192)) is False     # empty -> false
+
+
+def test_fast_aggregate_verify_32768(m, cache):
+    """Config 3 shape: 32 768 distinct keys, one message, aggregate signature (C restatement as generator
+    and checker): same aggregate point bit-exactly, same verdicts."""
+    import c_oracle as co
+    n = 32768
+    sks = [int.from_bytes(hashlib.sha256(b"fav" + i.to_bytes(4, "little")).digest(), "little") % o.R or 1 for i in range(n)]
+    pks = b"".join(co.sk_to_pk(sk) for sk in sks)
+    msg = b"Mr F was here"
+    hm = co.hash_to_g2(msg, o.DST_SIG)
+    sig = co.g2_mul(hm, sum(sks) % o.R)
+    bad = co.g2_mul(hm, (sum(sks) + 1) % o.R)
+    assert o.g1_to_blst_affine(g1_jac_to_affine(m.aggregateAll(cache, pks))) == co.g1_sum(pks)
+    assert m.fastAggregateVerify(cache, pks, msg, sig) is True
+    print("timings(ms):", cache.timings())
+    assert m.fastAggregateVerify(cache, pks, msg, bad) is False
+    assert co.fast_aggregate_verify(pks, msg, sig) is True and co.fast_aggregate_verify(pks, msg, bad) is False
+    # dropping one key breaks it
+    assert m.fastAggregateVerify(cache, pks[96:], msg, sig) is False
