@@ -94,6 +94,18 @@ int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, size_t 
 int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* ctx, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
                                            const void* sig, void* stream);
 
+/* blst_p1s_mult_pippenger (blst_abi.nim:336-340; blst+nim.h:70-72; call sites benchmarks/bls12381_msm_g1.nim:50-59,
+ * blst_min_pubkey_sig_core.nim:629): ret = sum_i [k_i mod 2^nbits] P_i as blst_p1 (Jacobian, 144 B).
+ * points[0] -> npoints contiguous blst_p1_affine, scalars[0] -> npoints 32-byte little-endian scalars, both
+ * NULL-terminated pointer lists in HOST memory exactly as the reference passes them; nbits in 1..256.
+ * The device workspace is (re)sized inside the context on first use, so the scratch size is 0. */
+size_t mi355_bls_p1s_mult_pippenger_scratch_sizeof(size_t npoints);
+int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* const points[], size_t npoints,
+                                 const uint8_t* const scalars[], size_t nbits);
+/* same with both arrays resident in device memory */
+int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_points, size_t npoints,
+                                        const void* d_scalars, size_t nbits, void* stream);
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

@@ -59,6 +59,10 @@ def lib():
         L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p, vp]
+        L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.argtypes = [sz]
+        L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.restype = sz
+        L.mi355_bls_p1s_mult_pippenger.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
+        L.mi355_bls_p1s_mult_pippenger_device.argtypes = [vp, ctypes.c_char_p, vp, sz, vp, sz, vp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
@@ -200,3 +204,24 @@ def fastAggregateVerify(cache, publicKeys, message, signature):
     if n == 0:
         return False
     return bool(_check(lib().mi355_bls_fast_aggregate_verify(cache._h, buf, n, bytes(message), len(message), bytes(signature))))
+
+
+def p1s_mult_pippenger(cache, points, scalars, nbits=255):
+    """blst_p1s_mult_pippenger shape (benchmarks/bls12381_msm_g1.nim:50-59): points = n x 96-byte affine,
+    scalars = n x 32-byte little-endian; returns the 144-byte blst_p1 (Jacobian) result."""
+    if len(points) % 96 or len(scalars) % 32 or len(points) // 96 != len(scalars) // 32:
+        raise ValueError("points: n x 96 bytes, scalars: n x 32 bytes")
+    n = len(points) // 96
+    pb = ctypes.create_string_buffer(bytes(points), len(points)) if n else None
+    sb = ctypes.create_string_buffer(bytes(scalars), len(scalars)) if n else None
+    pl = (ctypes.c_void_p * 2)(ctypes.addressof(pb) if n else None, None)       # [ptr, NULL]
+    sl = (ctypes.c_void_p * 2)(ctypes.addressof(sb) if n else None, None)
+    out = ctypes.create_string_buffer(144)
+    _check(lib().mi355_bls_p1s_mult_pippenger(cache._h, out, pl, n, sl, nbits))
+    return out.raw
+
+
+def p1s_mult_pippenger_device(cache, d_points, n, d_scalars, nbits=255, stream=0):
+    out = ctypes.create_string_buffer(144)
+    _check(lib().mi355_bls_p1s_mult_pippenger_device(cache._h, out, d_points, n, d_scalars, nbits, stream))
+    return out.raw

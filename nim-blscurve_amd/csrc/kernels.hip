@@ -536,6 +536,150 @@ __global__ void k_fav_setup(const uint32_t* __restrict__ agg, const uint32_t* __
     soa_st_g2(H, stride, 1, jac_from_aff(sg));
 }
 
+// ------------------------------------------------------------------------------------------
+// G1 Pippenger multi-scalar multiplication: sum_i [k_i mod 2^nbits] P_i   (replaces
+// blst_p1s_mult_pippenger, blst_abi.nim:336-340; shape of benchmarks/bls12381_msm_g1.nim:22-59).
+//   k_msm_hist     per point: window digits -> bucket histogram (global atomics)
+//   k_msm_scan     per window: exclusive scan of the histogram -> bucket offsets
+//   k_msm_scatter  per point: point index into its bucket's slice, per window (counting sort)
+//   k_msm_bucket   one lane per (window, bucket): sum of its points with mixed additions
+//   k_msm_segred   one lane per segment of L buckets: running sums -> sum_b b*B_b of the segment
+//   k_msm_winsum   per window: sum of its segment values (wave-shuffle tree), times 2^(c*w)
+//   k_msm_final    sum over windows
+// Buckets live in HBM as SoA Jacobian points (151 MB at 16 windows x 2^16 buckets).
+// ------------------------------------------------------------------------------------------
+// Window w covers bits [off_w, off_w + len_w): the nbits are split into nwin windows whose widths differ by
+// at most one bit (wbase + 1 for the first wrem windows, wbase after) so that no window is short and
+// concentrates the points into a few buckets.
+struct msm_win {
+    uint32_t nwin, wbase, wrem;
+};
+__device__ __forceinline__ uint32_t msm_win_off(const msm_win& W, uint32_t w) {
+    return w < W.wrem ? w * (W.wbase + 1) : W.wrem * (W.wbase + 1) + (w - W.wrem) * W.wbase;
+}
+__device__ __forceinline__ uint32_t msm_digit(const uint8_t* __restrict__ sc, size_t i, uint32_t w, const msm_win& W) {
+    uint32_t bit0 = msm_win_off(W, w);
+    uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase;
+    const uint8_t* p = sc + i * 32;
+    uint32_t byte0 = bit0 >> 3;
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < 4 && byte0 + j < 32; j++) v |= (uint64_t)p[byte0 + j] << (8 * j);
+    return (uint32_t)(v >> (bit0 & 7)) & ((1u << len) - 1u);
+}
+__global__ void __launch_bounds__(WAVE) k_msm_hist(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c, uint32_t* __restrict__ hist) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    for (uint32_t w = 0; w < W.nwin; w++) {
+        uint32_t d = msm_digit(sc, i, w, W);
+        if (d) atomicAdd(&hist[((size_t)w << c) | d], 1u);
+    }
+}
+// one wave per window
+__global__ void __launch_bounds__(WAVE) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t c, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+    uint32_t w = blockIdx.x, nb = 1u << c, per = (nb + WAVE - 1) / WAVE;
+    uint32_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    const uint32_t* h = hist + ((size_t)w << c);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += h[b];
+    uint32_t incl = sum;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, WAVE);
+        if ((int)threadIdx.x >= d) incl += o;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t b = lo; b < hi; b++) {
+        offs[((size_t)w << c) | b] = run;
+        cursor[((size_t)w << c) | b] = run;
+        run += h[b];
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    for (uint32_t w = 0; w < W.nwin; w++) {
+        uint32_t d = msm_digit(sc, i, w, W);
+        if (d) {
+            uint32_t pos = atomicAdd(&cursor[((size_t)w << c) | d], 1u);
+            sorted[(size_t)w * n + pos] = i;
+        }
+    }
+}
+// lane per (window, bucket); `order` (optional) lists the buckets so that a wave's lanes have similar counts
+__global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint8_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t c,
+                                                     uint32_t total, uint4* __restrict__ buckets) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= total) return;
+    uint32_t g = order ? order[t] : t;
+    uint32_t w = g >> c, cnt = hist[g], off = offs[g];
+    const uint32_t* srt = sorted + (size_t)w * n + off;
+    g1_jac acc = jac_inf<fp>();
+    for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(pts + (size_t)srt[j] * 96);
+        g1_aff q{ld_fp_words(pw), ld_fp_words(pw + 12)};
+        acc = jac_add_aff(acc, q);
+    }
+    soa_st_g1(buckets, total, g, acc);
+}
+// buckets ordered by point count (descending) with a counting sort on min(count, 255)
+__global__ void __launch_bounds__(WAVE) k_msm_order_hist(const uint32_t* __restrict__ hist, uint32_t total, uint32_t* __restrict__ chist) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= total) return;
+    uint32_t cc = hist[t] > 255 ? 255 : hist[t];
+    atomicAdd(&chist[255 - cc], 1u);
+}
+__global__ void k_msm_order_scan(uint32_t* __restrict__ chist) {     // 256 bins, one lane
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int i = 0; i < 256; i++) { uint32_t v = chist[i]; chist[i] = run; run += v; }
+}
+__global__ void __launch_bounds__(WAVE) k_msm_order_scatter(const uint32_t* __restrict__ hist, uint32_t total, uint32_t* __restrict__ chist, uint32_t* __restrict__ order) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= total) return;
+    uint32_t cc = hist[t] > 255 ? 255 : hist[t];
+    order[atomicAdd(&chist[255 - cc], 1u)] = t;
+}
+// lane per (window, segment of L buckets): W = sum_{b in seg} b * B_b
+__global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ buckets, uint32_t total, uint32_t c, uint32_t L, uint32_t nseg_total,
+                                                     uint4* __restrict__ segout) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= nseg_total) return;
+    uint32_t segs_per_win = (1u << c) / L;
+    uint32_t w = t / segs_per_win, b0 = (t % segs_per_win) * L;
+    g1_jac S = jac_inf<fp>(), T = jac_inf<fp>();
+    for (uint32_t j = L; j-- > 0;) {
+        g1_jac B = soa_ld_g1(buckets, total, ((size_t)w << c) | (b0 + j));
+        S = jac_add(S, B);
+        T = jac_add(T, S);            // T = sum (j+1) * B_{b0+j}
+    }
+    // W = T + (b0 - 1) * S
+    g1_jac acc = jac_inf<fp>();
+    for (int i = 31; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((b0 >> i) & 1) acc = jac_add(acc, S);
+    }
+    acc = jac_add(acc, jac_neg(S));
+    acc = jac_add(acc, T);
+    soa_st_g1(segout, nseg_total, t, acc);
+}
+// one wave per window: R_w = sum of its segment values, then 2^(c*w) * R_w
+__global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, msm_win W, uint32_t* __restrict__ winout) {
+    uint32_t w = blockIdx.x;
+    g1_jac acc = jac_inf<fp>();
+    for (uint32_t j = threadIdx.x; j < segs_per_win; j += WAVE) acc = jac_add(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
+    for (int d = 32; d >= 1; d >>= 1) {
+        g1_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t sh = msm_win_off(W, w);
+        for (uint32_t i = 0; i < sh; i++) acc = jac_dbl(acc);
+        uint32_t* o = winout + (size_t)w * 36;
+        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+    }
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -559,6 +703,21 @@ __global__ void k_export_g1(const uint4* __restrict__ P, size_t stride, uint32_t
 // ------------------------------------------------------------------------------------------
 // Context
 // ------------------------------------------------------------------------------------------
+struct msm_ws {
+    size_t cap_n = 0;
+    uint32_t cap_total = 0, cap_seg = 0;
+    uint8_t* d_pts = nullptr;
+    uint8_t* d_sc = nullptr;
+    uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr;
+    uint4 *buckets = nullptr, *segout = nullptr;
+};
+static void msm_free(msm_ws* m) {
+    void* b[] = {m->d_pts, m->d_sc, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout};
+    for (void* x : b)
+        if (x) (void)hipFree(x);
+    *m = msm_ws();
+}
+
 struct mi355_bls_ctx {
     int device = 0;
     size_t cap = 0;          // max sets
@@ -590,6 +749,7 @@ struct mi355_bls_ctx {
     bool have_gt = false;
     float timings[8] = {};
     dst_t dst;
+    msm_ws* msm = nullptr;           // lazily sized MSM workspace
 };
 
 static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
@@ -606,6 +766,10 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->msm) {
+        msm_free(c->msm);
+        delete c->msm;
+    }
     delete c;
 }
 
@@ -621,6 +785,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     HIPCHK(hipSetDevice(device));
     auto* c = new mi355_bls_ctx();
     c->device = device;
+    c->msm = new msm_ws();
     c->cap = max_sets;
     c->stride = ((max_sets + 1 + 63) / 64) * 64;
     std::memset(&c->dst, 0, sizeof(c->dst));
@@ -936,4 +1101,123 @@ extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_sets, pks, n * 96, hipMemcpyHostToDevice, nullptr));
     return mi355_bls_fast_aggregate_verify_device(c, c->d_sets, n, msg, msg_len, sig, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// blst_p1s_mult_pippenger replacement
+// ------------------------------------------------------------------------------------------
+static uint32_t msm_window_bits(size_t n) {
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return (uint32_t)c;
+}
+constexpr uint32_t MSM_SEG = 16;
+
+extern "C" size_t mi355_bls_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
+    (void)npoints;
+    return 0;          // blst_p1s_mult_pippenger_scratch_sizeof (blst_abi.nim:336): the workspace lives on the device
+}
+
+static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
+    msm_ws* m = c->msm;
+    uint32_t total = nwin << cb, nseg = total / MSM_SEG;
+    if (n <= m->cap_n && total <= m->cap_total) return 0;
+    size_t cn = n > m->cap_n ? n : m->cap_n;
+    uint32_t ct = total > m->cap_total ? total : m->cap_total;
+    msm_free(m);
+#define MALLOC(p, bytes)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = hipMalloc((void**)&(p), (bytes));                                  \
+        if (e_ != hipSuccess) {                                                            \
+            g_err = std::string("hipMalloc " #p ": ") + hipGetErrorString(e_);             \
+            msm_free(m);                                                                   \
+            return MI355_BLS_ERR_HIP;                                                      \
+        }                                                                                  \
+    } while (0)
+    MALLOC(m->d_pts, cn * 96);
+    MALLOC(m->d_sc, cn * 32);
+    MALLOC(m->hist, (size_t)ct * 4);
+    MALLOC(m->offs, (size_t)ct * 4);
+    MALLOC(m->cursor, (size_t)ct * 4);
+    MALLOC(m->order, (size_t)ct * 4);
+    MALLOC(m->chist, 256 * 4);
+    MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 64 windows (nbits 256 at c = 4)
+    MALLOC(m->buckets, (size_t)ct * 144);
+    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 144);
+    MALLOC(m->winout, 64 * 144);
+    MALLOC(m->out, 144);
+#undef MALLOC
+    m->cap_n = cn;
+    m->cap_total = ct;
+    m->cap_seg = nseg;
+    return 0;
+}
+
+extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars,
+                                                   size_t nbits, void* stream) {
+    if (!c || !ret_p1 || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
+    if (npoints == 0) {
+        memset(ret_p1, 0, 144);
+        return 0;
+    }
+    if (!d_points || !d_scalars) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t n = (uint32_t)npoints, c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
+    msm_win W{nwin, (uint32_t)nbits / nwin, (uint32_t)nbits % nwin};
+    uint32_t cb = W.wbase + (W.wrem ? 1 : 0);           // bucket index bits per window
+    if (cb < 4) cb = 4;                                  // at least one 16-bucket segment per window
+    int rc = msm_reserve(c, npoints, nwin, cb);
+    if (rc) return rc;
+    msm_ws* m = c->msm;
+    uint32_t total = nwin << cb, segs_per_win = (1u << cb) / MSM_SEG, nseg = nwin * segs_per_win;
+    const uint8_t* pts = (const uint8_t*)d_points;
+    const uint8_t* sc = (const uint8_t*)d_scalars;
+    uint32_t nbp = (n + WAVE - 1) / WAVE, nbt = (total + WAVE - 1) / WAVE;
+    HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
+    HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    k_msm_hist<<<nbp, WAVE, 0, st>>>(sc, n, W, cb, m->hist);
+    k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
+    k_msm_scatter<<<nbp, WAVE, 0, st>>>(sc, n, W, cb, m->cursor, m->sorted);
+    k_msm_order_hist<<<nbt, WAVE, 0, st>>>(m->hist, total, m->chist);
+    k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
+    k_msm_order_scatter<<<nbt, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    k_msm_bucket<<<nbt, WAVE, 0, st>>>(pts, m->sorted, m->offs, m->hist, m->order, n, cb, total, m->buckets);
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    k_msm_segred<<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, cb, MSM_SEG, nseg, m->segout);
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    k_msm_winsum<<<nwin, WAVE, 0, st>>>(m->segout, nseg, segs_per_win, W, m->winout);
+    k_g1_sum2<<<1, WAVE, 0, st>>>(m->winout, nwin, m->out);
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ret_p1, m->out, 144, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return collect_timings(c, 4);       // [0] sort, [1] bucket accumulation, [2] segment reduction, [3] window sums + doublings
+}
+
+// Same shape as blst_p1s_mult_pippenger incl. the NULL-terminated pointer-to-array convention
+// (blst+nim.h:70-72; benchmarks/bls12381_msm_g1.nim:52-59): points[0] / scalars[0] are contiguous
+// arrays of npoints blst_p1_affine / 32-byte little-endian scalars in HOST memory.
+extern "C" int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* const points[], size_t npoints,
+                                            const uint8_t* const scalars[], size_t nbits) {
+    if (!c || !ret_p1) return MI355_BLS_ERR_ARG;
+    if (npoints == 0) {
+        memset(ret_p1, 0, 144);
+        return 0;
+    }
+    if (!points || !points[0] || !scalars || !scalars[0] || nbits == 0 || nbits > 256) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
+    uint32_t cb = (uint32_t)nbits / nwin + (((uint32_t)nbits % nwin) ? 1 : 0);
+    if (cb < 4) cb = 4;
+    int rc = msm_reserve(c, npoints, nwin, cb);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->msm->d_pts, points[0], npoints * 96, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars[0], npoints * 32, hipMemcpyHostToDevice, nullptr));
+    return mi355_bls_p1s_mult_pippenger_device(c, ret_p1, c->msm->d_pts, npoints, c->msm->d_sc, nbits, nullptr);
 }
