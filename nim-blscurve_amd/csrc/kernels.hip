@@ -567,12 +567,10 @@ __device__ __forceinline__ uint32_t msm_digit(const uint8_t* __restrict__ sc, si
     return (uint32_t)(v >> (bit0 & 7)) & ((1u << len) - 1u);
 }
 __global__ void __launch_bounds__(WAVE) k_msm_hist(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c, uint32_t* __restrict__ hist) {
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;       // lane per (point, window)
     if (i >= n) return;
-    for (uint32_t w = 0; w < W.nwin; w++) {
-        uint32_t d = msm_digit(sc, i, w, W);
-        if (d) atomicAdd(&hist[((size_t)w << c) | d], 1u);
-    }
+    uint32_t d = msm_digit(sc, i, w, W);
+    if (d) atomicAdd(&hist[((size_t)w << c) | d], 1u);
 }
 // one wave per window
 __global__ void __launch_bounds__(WAVE) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t c, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
@@ -595,14 +593,12 @@ __global__ void __launch_bounds__(WAVE) k_msm_scan(const uint32_t* __restrict__ 
 }
 __global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
     if (i >= n) return;
-    for (uint32_t w = 0; w < W.nwin; w++) {
-        uint32_t d = msm_digit(sc, i, w, W);
-        if (d) {
-            uint32_t pos = atomicAdd(&cursor[((size_t)w << c) | d], 1u);
-            sorted[(size_t)w * n + pos] = i;
-        }
+    uint32_t d = msm_digit(sc, i, w, W);
+    if (d) {
+        uint32_t pos = atomicAdd(&cursor[((size_t)w << c) | d], 1u);
+        sorted[(size_t)w * n + pos] = i;
     }
 }
 // lane per (window, bucket); `order` (optional) lists the buckets so that a wave's lanes have similar counts
@@ -623,11 +619,24 @@ __global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint8_t* __restrict__
     soa_st_g1(buckets, total, g, acc);
 }
 // buckets ordered by point count (descending) with a counting sort on min(count, 255)
+// Each wave bins MSM_ORD_PER buckets per lane into an LDS histogram first, so the 256 global bins see
+// one atomic per (wave, bin) instead of one per bucket.
+constexpr uint32_t MSM_ORD_PER = 16;
 __global__ void __launch_bounds__(WAVE) k_msm_order_hist(const uint32_t* __restrict__ hist, uint32_t total, uint32_t* __restrict__ chist) {
-    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
-    if (t >= total) return;
-    uint32_t cc = hist[t] > 255 ? 255 : hist[t];
-    atomicAdd(&chist[255 - cc], 1u);
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += WAVE) h[i] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * WAVE * MSM_ORD_PER;
+    for (uint32_t j = 0; j < MSM_ORD_PER; j++) {
+        uint32_t t = base + j * WAVE + threadIdx.x;
+        if (t < total) {
+            uint32_t cc = hist[t] > 255 ? 255 : hist[t];
+            atomicAdd(&h[255 - cc], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += WAVE)
+        if (h[i]) atomicAdd(&chist[i], h[i]);
 }
 __global__ void k_msm_order_scan(uint32_t* __restrict__ chist) {     // 256 bins, one lane
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -635,10 +644,28 @@ __global__ void k_msm_order_scan(uint32_t* __restrict__ chist) {     // 256 bins
     for (int i = 0; i < 256; i++) { uint32_t v = chist[i]; chist[i] = run; run += v; }
 }
 __global__ void __launch_bounds__(WAVE) k_msm_order_scatter(const uint32_t* __restrict__ hist, uint32_t total, uint32_t* __restrict__ chist, uint32_t* __restrict__ order) {
-    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
-    if (t >= total) return;
-    uint32_t cc = hist[t] > 255 ? 255 : hist[t];
-    order[atomicAdd(&chist[255 - cc], 1u)] = t;
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += WAVE) h[i] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * WAVE * MSM_ORD_PER;
+    uint32_t rank[MSM_ORD_PER], bin[MSM_ORD_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < MSM_ORD_PER; j++) {
+        uint32_t t = base + j * WAVE + threadIdx.x;
+        bin[j] = 0xffffffffu;
+        if (t < total) {
+            uint32_t cc = hist[t] > 255 ? 255 : hist[t];
+            bin[j] = 255 - cc;
+            rank[j] = atomicAdd(&h[bin[j]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += WAVE)
+        if (h[i]) h[i] = atomicAdd(&chist[i], h[i]);       // h[i] <- global base of this wave's run in bin i
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < MSM_ORD_PER; j++)
+        if (bin[j] != 0xffffffffu) order[h[bin[j]] + rank[j]] = base + j * WAVE + threadIdx.x;
 }
 // lane per (window, segment of L buckets): W = sum_{b in seg} b * B_b
 __global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ buckets, uint32_t total, uint32_t c, uint32_t L, uint32_t nseg_total,
@@ -663,11 +690,28 @@ __global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ b
     acc = jac_add(acc, T);
     soa_st_g1(segout, nseg_total, t, acc);
 }
-// one wave per window: R_w = sum of its segment values, then 2^(c*w) * R_w
-__global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, msm_win W, uint32_t* __restrict__ winout) {
+// grid (nwin, nsplit): partial sums of a window's segment values
+__global__ void __launch_bounds__(WAVE) k_msm_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t* __restrict__ part) {
+    uint32_t w = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
+    g1_jac acc = jac_inf<fp>();
+    for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit) acc = jac_add(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
+    for (int d = 32; d >= 1; d >>= 1) {
+        g1_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* o = part + ((size_t)w * nsplit + sp) * 36;
+        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+    }
+}
+// one wave per window: R_w = sum of its nsplit partial sums, then 2^(off_w) * R_w
+__global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, msm_win W, uint32_t* __restrict__ winout) {
     uint32_t w = blockIdx.x;
     g1_jac acc = jac_inf<fp>();
-    for (uint32_t j = threadIdx.x; j < segs_per_win; j += WAVE) acc = jac_add(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
+    for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) {
+        const uint32_t* o = part + ((size_t)w * nsplit + j) * 36;
+        acc = jac_add(acc, g1_jac{ld_fp_words(o), ld_fp_words(o + 12), ld_fp_words(o + 24)});
+    }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
         acc = jac_add(acc, o);
@@ -1180,18 +1224,21 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
     HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
-    k_msm_hist<<<nbp, WAVE, 0, st>>>(sc, n, W, cb, m->hist);
+    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->hist);
     k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
-    k_msm_scatter<<<nbp, WAVE, 0, st>>>(sc, n, W, cb, m->cursor, m->sorted);
-    k_msm_order_hist<<<nbt, WAVE, 0, st>>>(m->hist, total, m->chist);
+    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->cursor, m->sorted);
+    uint32_t nbo = (total + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
+    k_msm_order_hist<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist);
     k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
-    k_msm_order_scatter<<<nbt, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
+    k_msm_order_scatter<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_msm_bucket<<<nbt, WAVE, 0, st>>>(pts, m->sorted, m->offs, m->hist, m->order, n, cb, total, m->buckets);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_msm_segred<<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, cb, MSM_SEG, nseg, m->segout);
     HIPCHK(hipEventRecord(c->ev[3], st));
-    k_msm_winsum<<<nwin, WAVE, 0, st>>>(m->segout, nseg, segs_per_win, W, m->winout);
+    uint32_t nsplit = segs_per_win >= 1024 ? 16 : (segs_per_win >= 128 ? 4 : 1);
+    k_msm_winpart<<<dim3(nwin, nsplit), WAVE, 0, st>>>(m->segout, nseg, segs_per_win, reinterpret_cast<uint32_t*>(m->buckets));
+    k_msm_winsum<<<nwin, WAVE, 0, st>>>(reinterpret_cast<const uint32_t*>(m->buckets), nsplit, W, m->winout);
     k_g1_sum2<<<1, WAVE, 0, st>>>(m->winout, nwin, m->out);
     HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(hipGetLastError());
