@@ -238,6 +238,22 @@ __device__ __forceinline__ g2_jac ld_g2_words(const uint32_t* o) {
                   fp2{ld_fp_words(o + 48), ld_fp_words(o + 60)}};
 }
 
+// level 1 of the partial-sum reduction: block b folds partials b, b+gridDim.x, ... -> part2[b]
+__global__ void __launch_bounds__(WAVE) k_sigsum1(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ part2) {
+    g2_jac acc = jac_inf<fp2>();
+    for (uint32_t j = blockIdx.x * WAVE + threadIdx.x; j < nparts; j += WAVE * gridDim.x) acc = jac_add(acc, ld_g2_words(part + (size_t)j * 72));
+    for (int d = 32; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* o = part2 + (size_t)blockIdx.x * 72;
+        st_fp_words(o, acc.x.c0); st_fp_words(o + 12, acc.x.c1);
+        st_fp_words(o + 24, acc.y.c0); st_fp_words(o + 36, acc.y.c1);
+        st_fp_words(o + 48, acc.z.c0); st_fp_words(o + 60, acc.z.c1);
+    }
+}
+
 // one wave: sum of the partials -> AggrSign; stored as Q of pair `slot` with P = -G1 (affine, Z = 1)
 __global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ part, uint32_t nparts, uint4* __restrict__ H, uint4* __restrict__ P,
                                                  size_t stride, size_t slot, uint32_t* __restrict__ agg_out) {
@@ -851,7 +867,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_H, c->stride * 288);
     ALLOC(c->d_P, c->stride * 144);
     ALLOC(c->d_lines, c->stride * 288 * (size_t)N_LINES);
-    ALLOC(c->d_spart, nwaves * 288);
+    ALLOC(c->d_spart, (nwaves + 16) * 288);
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
     ALLOC(c->d_msg, 4096 + 192);
@@ -909,7 +925,13 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[3], st));
     k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_spart);
-    k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
+    if (nb > 64) {          // two-level fold: 16 waves, then one
+        uint32_t* part2 = c->d_spart + (size_t)nb * 72;
+        k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
+        k_sigsum<<<1, WAVE, 0, st>>>(part2, 16, c->d_H, c->d_P, c->stride, n, c->d_agg);
+    } else {
+        k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
+    }
     HIPCHK(hipEventRecord(c->ev[4], st));
     // The n tuple pairs fill the chip's wave slots exactly at n = 64 * slots; the extra (AggrSign, -G1)
     // pair would cost a whole second round, so its 68 lines are produced by one side-stream wave that
@@ -926,7 +948,10 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         k_lines<<<nb1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
         HIPCHK(hipEventRecord(c->ev[5], st));
     }
-    uint32_t nblk = c->slots / N_LINES;
+    // workgroups are dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first one:
+    // leave one free wave slot per XCD so the side-stream wave really runs beside k_lineprod
+    uint32_t nblk = (c->slots > 8 ? c->slots - 8 : c->slots) / N_LINES;
+    if (!use_side) nblk = c->slots / N_LINES;
     if (nblk < 1) nblk = 1;
     if (nblk > c->nblk_cap) nblk = c->nblk_cap;
     uint32_t m = (n32 + WAVE * nblk - 1) / (WAVE * nblk);
