@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="tuples per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="tuples in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the fastAggregateVerify / MSM side measurements")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,11 +65,9 @@ def main():
     d_sets = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
     rnd = bytearray(co_sha256(co, b"Mr F was here"))
 
-    cache = m.BatchedBLSVerifierCache.init(max_sets=n, device=local)
     n_total = n * world
-    nthreads = cache.numThreads * world                     # global number of blinding chains
-    if world > 1:
-        m._check(m.lib().mi355_bls_ctx_set_num_threads(cache._h, nthreads))
+    nthreads = m.DEFAULT_NUM_THREADS * world                # global number of blinding chains
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)
     stream = torch.cuda.current_stream().cuda_stream
 
     import importlib.util
@@ -140,12 +139,67 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_gen_s": round(gen_s, 1),
         }
+        out["roofline"]["traffic"] = pmc_traffic(dom)
+        if not a.no_aux:
+            out["aux"] = aux_rows(m, co, cache, dev)
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(co, a.cpu_sample, bytes(rnd))
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+STAGE_KERNEL = {"hash_to_g2": "k_hash", "pk_mul": "k_pkmul", "sig_mul_sum": "k_sigmul", "miller_lines": "k_lines",
+                "line_products": "k_lineprod", "final": "k_tail", "blinding": "k_blind"}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is committed for that kernel."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        return d[STAGE_KERNEL[stage]]["hbm_bytes_corrected"]
+    except Exception:
+        return None
+
+
+def aux_rows(m, co, cache, dev):
+    """Side measurements of the other BASELINE.json configs (not the headline metric):
+    config 3 fastAggregateVerify with 32 768 keys, config 4 G1 Pippenger MSM with 2^20 points."""
+    import random
+    import numpy as np
+    out = {}
+    n = 32768
+    pks, sksum = co.make_pks(n, seed=1 << 41)
+    msg = b"Mr F was here"
+    sig = co.g2_mul(co.hash_to_g2(msg, b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"), sksum)
+    d_pks = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    fav = lambda: m._check(m.lib().mi355_bls_fast_aggregate_verify_device(cache._h, d_pks.data_ptr(), n, msg, len(msg), sig, 0))
+    assert fav() == 1
+    t0 = time.perf_counter()
+    for _ in range(3):
+        assert fav() == 1
+    t = cache.timings()
+    out["fastAggregateVerify_32768"] = {"ms_per_call": (time.perf_counter() - t0) / 3 * 1e3, "g1_sum_ms": t["blinding"],
+                                        "g1_sum_GBs_at_96B_per_key": 96.0 * n / (t["blinding"] * 1e-3) / 1e9,
+                                        "note": "one pairing per call: latency-bound (single-lane hash-to-G2 + 2-pair Miller loop + final exponentiation)"}
+    nm = 1 << 20
+    rng = random.Random(7)
+    base = [co.sk_to_pk(rng.getrandbits(96) | 1) for _ in range(2048)]
+    pts = b"".join(base[i % 2048] for i in range(nm))
+    sc = np.random.default_rng(7).integers(0, 256, size=(nm, 32), dtype=np.uint8).tobytes()
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+    ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
+    m.p1s_mult_pippenger_device(cache, dp.data_ptr(), nm, ds.data_ptr(), 255)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.p1s_mult_pippenger_device(cache, dp.data_ptr(), nm, ds.data_ptr(), 255)
+    dt = (time.perf_counter() - t0) / 3
+    out["g1_msm_2^20"] = {"points_per_s": nm / dt, "ms_per_call": dt * 1e3, "nbits": 255,
+                          "GBs_at_128B_per_point": 128.0 * nm / dt / 1e9}
+    return out
 
 
 def co_sha256(co, b):
@@ -173,7 +227,8 @@ def cpu_baseline(co, sample, rnd):
     assert ok
     return {"value": sample / dt, "unit": "verifications/s", "cores": cores, "kind": "port",
             "sample": "%d tuples of the same workload, batchVerifyParallel shape with %d threads, %.1f s "
-                      "(oracle/bls_oracle.c: plain-C restatement, not BLST)" % (sample, cores, dt)}
+                      "(oracle/bls_oracle.c: unoptimised plain-C restatement of the reference algorithm, not BLST; "
+                      "BLST's assembly is several times faster per core)" % (sample, cores, dt)}
 
 
 if __name__ == "__main__":

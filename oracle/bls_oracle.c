@@ -526,6 +526,15 @@ void oracle_make_batch(uint8_t* sets, size_t n, uint64_t seed) {
         oracle_sk_to_pk(sk, o); memcpy(o + 96, msg, 32); oracle_sign(sk, msg, 32, o + 128);
     }
 }
+/* public keys of the same secret keys oracle_make_batch derives: sk_i = SHA256("sk" || LE64(seed+i)), top 2 bits cleared, bit 0 set */
+void oracle_make_pks(uint8_t* pks, size_t n, uint64_t seed) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < (long)n; i++) {
+        uint8_t sk[32], in[10] = {'s', 'k'};
+        u64_le(in + 2, seed + (uint64_t)i); oracle_sha256(in, 10, sk); sk[31] &= 0x3f; sk[0] |= 1;
+        oracle_sk_to_pk(sk, pks + 96 * (size_t)i);
+    }
+}
 /* sum of affine G1 points (aggregateAll, core :179-195) -> affine */
 void oracle_g1_sum(const uint8_t* pts, size_t n, uint8_t out96[96]) {
     g1j acc = g1_inf();

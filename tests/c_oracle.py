@@ -19,6 +19,7 @@ def lib():
         L.oracle_sign.argtypes = [cp, cp, sz, cp]
         L.oracle_g2_mul.argtypes = [cp, cp, cp]
         L.oracle_make_batch.argtypes = [vp, sz, ctypes.c_uint64]
+        L.oracle_make_pks.argtypes = [vp, sz, ctypes.c_uint64]
         L.oracle_g1_sum.argtypes = [cp, sz, cp]
         L.oracle_fast_aggregate_verify.argtypes = [cp, sz, cp, sz, cp]
         L.oracle_msm_g1.argtypes = [cp, cp, sz, i32, cp]
@@ -84,3 +85,18 @@ def msm_g1(pts, scalars, nbits=255):
     o = ctypes.create_string_buffer(96)
     lib().oracle_msm_g1(pts, scalars, len(pts) // 96, nbits, o)
     return o.raw
+
+
+def make_pks(n, seed=0):
+    """(pks, sum of the secret keys mod r) for the keys oracle_make_batch derives."""
+    import hashlib
+    R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    b = ctypes.create_string_buffer(96 * n)
+    lib().oracle_make_pks(b, n, seed)
+    tot = 0
+    for i in range(n):
+        sk = bytearray(hashlib.sha256(b"sk" + (seed + i).to_bytes(8, "little")).digest())
+        sk[31] &= 0x3f
+        sk[0] |= 1
+        tot += int.from_bytes(sk, "little")
+    return b.raw, tot % R
