@@ -24,6 +24,9 @@ BLS_HD fp2 f_neg(const fp2& a) { return fp2_neg(a); }
 BLS_HD fp2 f_dbl(const fp2& a) { return fp2_dbl(a); }
 BLS_HD bool f_is_zero(const fp2& a) { return fp2_is_zero(a); }
 BLS_HD fp2 f_select(bool c, const fp2& a, const fp2& b) { return fp2_select(c, a, b); }
+// partial reduction (|v| < 0.51p): applied to stored coordinates so value bounds never accumulate
+BLS_HD fp f_red(const fp& a) { return fp_reduce(a); }
+BLS_HD fp2 f_red(const fp2& a) { return fp2_reduce(a); }
 template <class F>
 BLS_HD F f_zero();
 template <>
@@ -79,10 +82,10 @@ BLS_MID jac<F> jac_dbl(const jac<F>& p) {
     F E = f_add(f_dbl(A), A);
     F Fq = f_sqr(E);
     jac<F> r;
-    r.x = f_sub(Fq, f_dbl(D));
+    r.x = f_red(f_sub(Fq, f_dbl(D)));
     F C8 = f_dbl(f_dbl(f_dbl(C)));
-    r.y = f_sub(f_mul(E, f_sub(D, r.x)), C8);
-    r.z = f_dbl(f_mul(p.y, p.z));
+    r.y = f_red(f_sub(f_mul(E, f_sub(D, r.x)), C8));
+    r.z = f_red(f_dbl(f_mul(p.y, p.z)));
     return r;
 }
 
@@ -102,9 +105,9 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     F HHH = f_mul(H, HH);
     F V = f_mul(p.x, HH);
     jac<F> r;
-    r.x = f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V));
-    r.y = f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH));
-    r.z = f_mul(p.z, H);   // = 0 when P == -Q
+    r.x = f_red(f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V)));
+    r.y = f_red(f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH)));
+    r.z = f_red(f_mul(p.z, H));   // = 0 when P == -Q
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, jac_from_aff(q), r);
     return r;
@@ -129,9 +132,9 @@ BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
     F HHH = f_mul(H, HH);
     F V = f_mul(U1, HH);
     jac<F> r;
-    r.x = f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V));
-    r.y = f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH));
-    r.z = f_mul(f_mul(p.z, q.z), H);
+    r.x = f_red(f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V)));
+    r.y = f_red(f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH)));
+    r.z = f_red(f_mul(f_mul(p.z, q.z), H));
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, q, r);
     return r;

@@ -1,10 +1,25 @@
 // Fp = GF(p), BLS12-381 base field, for gfx950 lanes.
 //
-// Representation: 12 x 32-bit little-endian limbs in Montgomery form, R = 2^384 -- byte-identical
-// to the reference's in-memory blst_fp (6 x u64 LE Montgomery limbs, blst_abi.nim:87-94), so
-// SignatureSet records are consumed without conversion.  Values are kept fully reduced (< p).
-// The inner product step is a 32x32+64 multiply-add (v_mad_u64_u32 on CDNA4); MFMA is not used:
-// carry-propagated multi-precision arithmetic is not a dense contraction.
+// Representation: 14 limbs of 28 bits in 32-bit words, Montgomery form with R = 2^392.
+// Why not the reference's 12 x 32 / 6 x 64 saturated limbs (blst_fp, blst_abi.nim:87-94)?  CDNA4's
+// integer multiplier is v_mad_u64_u32 (32x32 + 64 -> 64).  It has a carry-OUT but no carry-IN, so a
+// saturated multi-precision MAC needs a second instruction (v_addc_co_u32) per partial product.  With
+// 28-bit limbs a whole Montgomery column -- up to 14 a_i*b_j plus 14 m_i*p_j products of < 2^60 -- sums
+// in one 64-bit accumulator without overflow: one instruction per partial product (392 per field
+// multiplication), no carry chains, and the compiler emits exactly that from plain C++.
+// MFMA is not used: this is per-lane multi-precision arithmetic, not a dense contraction.
+//
+// Limbs are SIGNED (two's complement in the 32-bit word; products use v_mad_i64_i32) and values are
+// "semi-normalised": limbs 0..12 in [-4, 2^28 + 4), limb 13 holds the signed excess, and the VALUE is only
+// bounded in magnitude by a small multiple of p (never reduced into [0, p) except by fp_canon).
+// Additions and subtractions are limb-wise plus ONE parallel carry step (no sequential carry chain, no
+// conditional subtraction, no bias constant), so value bounds grow additively.  fp_mul accepts limbs of
+// magnitude < 2^30 and value bounds whose product is <= 2048 p^2, and returns a value in (-2p, 2p).
+// The host test build (-DBLS_TRACK_BOUNDS, tests/host_emu) carries a worst-case magnitude bound with
+// every element and asserts these preconditions on every operation, independent of the data.
+//
+// The reference's memory image (12 x 32-bit limbs, R = 2^384) is converted at the boundary only
+// (fp_from_blst / fp_to_blst: one multiplication each).
 //
 // All functions are __host__ __device__ so that tests/host_emu can execute the exact kernel
 // arithmetic on the build container's CPU (there is no GPU there); the product only ever calls
@@ -25,163 +40,182 @@
 #define BLS_CONST static constexpr
 #include "constants.hpp"
 
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#include <execinfo.h>
+#define BLS_VB_FIELD uint32_t vb;
+#define BLS_SET_VB(x, v) ((x).vb = (v))
+#define BLS_VB(x) ((x).vb)
+#define BLS_REQUIRE(cond, what)                                                         \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            std::fprintf(stderr, "fp bound violation: %s (%s:%d)\n", what, __FILE__, __LINE__); \
+            void* bt_[24];                                                              \
+            backtrace_symbols_fd(bt_, backtrace(bt_, 24), 2);                           \
+            std::abort();                                                               \
+        }                                                                               \
+    } while (0)
+#else
+#define BLS_VB_FIELD
+#define BLS_SET_VB(x, v) ((void)0)
+#define BLS_VB(x) 0u
+#define BLS_REQUIRE(cond, what) ((void)0)
+#endif
+
 namespace bls {
 
+constexpr int FP_N = 14;
+constexpr uint32_t FP_MASK = 0x0fffffffu;
+
 struct fp {
-    uint32_t l[12];
+    uint32_t l[FP_N];
+    BLS_VB_FIELD
 };
 
-BLS_HD fp fp_from_const(const uint32_t (&c)[12]) {
+BLS_HD fp fp_from_const(const uint32_t (&c)[FP_N]) {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = c[i];
+    for (int i = 0; i < FP_N; i++) r.l[i] = c[i];
+    BLS_SET_VB(r, 1);
     return r;
 }
 
 BLS_HD fp fp_zero() {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = 0;
+    for (int i = 0; i < FP_N; i++) r.l[i] = 0;
+    BLS_SET_VB(r, 1);
     return r;
 }
 
 BLS_HD fp fp_one() { return fp_from_const(k::ONE); }
 
-BLS_HD bool fp_is_zero(const fp& a) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) acc |= a.l[i];
-    return acc == 0;
-}
-
-BLS_HD bool fp_eq(const fp& a, const fp& b) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) acc |= a.l[i] ^ b.l[i];
-    return acc == 0;
-}
-
 // r = c ? a : b
 BLS_HD fp fp_select(bool c, const fp& a, const fp& b) {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    for (int i = 0; i < FP_N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    BLS_SET_VB(r, BLS_VB(a) > BLS_VB(b) ? BLS_VB(a) : BLS_VB(b));
     return r;
 }
 
-// t (12 limbs + carry bit) -> t mod p, given t < 2p
-BLS_HD fp fp_reduce_once(const uint32_t (&t)[12], uint32_t top) {
-    uint32_t d[12];
-    uint64_t borrow = 0;
+// one parallel carry step (arithmetic shifts: limbs may be slightly negative): |limbs| < 2^31 in,
+// limbs 0..12 in [-4, 2^28 + 4) out, limb 13 absorbs the rest
+BLS_HD void fp_carry_step(uint32_t (&s)[FP_N]) {
+    uint32_t c[FP_N - 1];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t v = (uint64_t)t[i] - k::P[i] - borrow;
-        d[i] = (uint32_t)v;
-        borrow = (v >> 32) & 1;
-    }
-    // t >= p  <=>  top set, or no final borrow
-    bool ge = top != 0 || borrow == 0;
-    fp r;
+    for (int i = 0; i < FP_N - 1; i++) c[i] = (uint32_t)((int32_t)s[i] >> 28);
+    s[0] &= FP_MASK;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = ge ? d[i] : t[i];
-    return r;
+    for (int i = 1; i < FP_N - 1; i++) s[i] = (s[i] & FP_MASK) + c[i - 1];
+    s[FP_N - 1] += c[FP_N - 2];
 }
 
 BLS_HD fp fp_add(const fp& a, const fp& b) {
-    uint32_t t[12];
-    uint64_t c = 0;
+    fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t v = (uint64_t)a.l[i] + b.l[i] + c;
-        t[i] = (uint32_t)v;
-        c = v >> 32;
-    }
-    return fp_reduce_once(t, (uint32_t)c);
+    for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] + b.l[i];
+    fp_carry_step(r.l);
+    BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    BLS_REQUIRE(BLS_VB(r) <= 1024, "fp_add value bound");
+    return r;
+}
+
+// limb-wise sum / difference with no carry step: |limbs| up to 2^29 + ..., only to be fed to fp_mul
+BLS_HD fp fp_add_nc(const fp& a, const fp& b) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] + b.l[i];
+    BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    return r;
+}
+BLS_HD fp fp_sub_nc(const fp& a, const fp& b) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] - b.l[i];
+    BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    return r;
 }
 
 BLS_HD fp fp_sub(const fp& a, const fp& b) {
-    uint32_t t[12];
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t v = (uint64_t)a.l[i] - b.l[i] - borrow;
-        t[i] = (uint32_t)v;
-        borrow = (v >> 32) & 1;
-    }
-    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
     fp r;
-    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t v = (uint64_t)t[i] + (k::P[i] & mask) + c;
-        r.l[i] = (uint32_t)v;
-        c = v >> 32;
-    }
+    for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] - b.l[i];
+    fp_carry_step(r.l);
+    BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    BLS_REQUIRE(BLS_VB(r) <= 1024, "fp_sub value bound");
     return r;
 }
 
 BLS_HD fp fp_neg(const fp& a) {
-    fp z = fp_zero();
-    return fp_sub(z, a);
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = 0u - a.l[i];
+    fp_carry_step(r.l);
+    BLS_SET_VB(r, BLS_VB(a));
+    return r;
 }
 
 BLS_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#include "fp_mul_gfx950.inc"
-// The multiplier body (~770 instructions, ~5.5 KB) is shared by every caller so that hot loops fit the
-// 64 KB instruction cache.  Operands travel in VGPRs: 24 scalar parameters map to v0..v23 and the
-// result returns in v0..v11 (aggregate by-reference parameters would go through scratch memory,
-// which at 65 536 lanes no longer fits L2).
-__device__ __noinline__ fp fp_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
-                                       uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
-                                       uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
-    fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11}};
-    return fp_mul_gfx950(a, b);
+// Montgomery product a*b*2^-392 mod p: product scanning, ONE signed 64-bit accumulator, 392 multiply-adds
+// (v_mad_i64_i32).  Column bound: 14 * (2^30)^2 + 14 * 2^56 + carry < 2^63.  m_k in [0, 2^28) makes the low 28
+// bits of the column vanish; the arithmetic shift is then an exact division.  Result in (-2p, 2p).
+BLS_HD fp fp_mul_core(const fp& a, const fp& b) {
+    int64_t acc = 0;
+    int32_t m[FP_N];
+    fp r;
+#pragma unroll
+    for (int kk = 0; kk < FP_N; kk++) {
+#pragma unroll
+        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+#pragma unroll
+        for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
+        acc += (int64_t)m[kk] * (int32_t)k::P[0];
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
+        acc >>= 28;
+    }
+    r.l[FP_N - 1] = (uint32_t)acc;
+    BLS_SET_VB(r, 2);
+    return r;
 }
-#endif
 
-// Montgomery product a*b*R^-1 mod p.  Device: product-scanning columns of v_mad_u64_u32 +
-// v_addc_co_u32 pairs (fp_mul_gfx950.inc).  Host (tests/host_emu only): portable CIOS with 32-bit
-// limbs; top word of p < 2^31 so 13 words suffice.
 #if defined(__HIP_DEVICE_COMPILE__)
+// The multiplier body (~500 instructions) is shared by every caller so that hot loops fit the 64 KB
+// instruction cache.  Operands travel in VGPRs: 28 scalar parameters map to v0..v27 and the result
+// returns in v0..v13 (aggregate by-reference parameters would go through scratch memory, which at
+// 65 536 lanes no longer fits L2).
+__device__ __noinline__ fp fp_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                       uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t b0, uint32_t b1,
+                                       uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9,
+                                       uint32_t b10, uint32_t b11, uint32_t b12, uint32_t b13) {
+    fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}};
+    return fp_mul_core(a, b);
+}
 __device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
-    return fp_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
-                       b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+    return fp_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13],
+                       b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13]);
 }
 #else
 __host__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
-    uint32_t t[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const uint32_t bi = b.l[i];
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            uint64_t v = (uint64_t)a.l[j] * bi + t[j] + c;
-            t[j] = (uint32_t)v;
-            c = v >> 32;
-        }
-        uint64_t v = (uint64_t)t[12] + c;
-        t[12] = (uint32_t)v;
-        const uint32_t m = t[0] * k::N0;
-        c = ((uint64_t)m * k::P[0] + t[0]) >> 32;
-#pragma unroll
-        for (int j = 1; j < 12; j++) {
-            uint64_t w = (uint64_t)m * k::P[j] + t[j] + c;
-            t[j - 1] = (uint32_t)w;
-            c = w >> 32;
-        }
-        uint64_t w = (uint64_t)t[12] + c;
-        t[11] = (uint32_t)w;
-        t[12] = (uint32_t)(w >> 32);
+#if defined(BLS_TRACK_BOUNDS)
+    BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(b) <= 2048, "fp_mul value bounds");
+    for (int i = 0; i < FP_N; i++) {
+        int64_t x = (int32_t)a.l[i], y = (int32_t)b.l[i];
+        BLS_REQUIRE(x > -(1ll << 30) && x < (1ll << 30) && y > -(1ll << 30) && y < (1ll << 30), "fp_mul limb bound");
     }
-    uint32_t lo[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) lo[i] = t[i];
-    return fp_reduce_once(lo, t[12]);
+#endif
+    return fp_mul_core(a, b);
 }
 #endif
 
@@ -190,16 +224,122 @@ BLS_HD fp fp_sqr(const fp& a) { return fp_mul(a, a); }
 // a * small constant via additions
 BLS_HD fp fp_mul3(const fp& a) { return fp_add(fp_dbl(a), a); }
 
-// Montgomery -> canonical integer limbs (multiply by 1)
-BLS_HD fp fp_from_mont(const fp& a) {
-    fp one = fp_zero();
-    one.l[0] = 1;
-    return fp_mul(a, one);
+// fully carried limbs (0..12 in [0, 2^28), limb 13 signed); the value is unchanged
+BLS_HD fp fp_carry_full(const fp& a) {
+    fp r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N - 1; i++) {
+        uint32_t v = a.l[i] + c;
+        r.l[i] = v & FP_MASK;
+        c = (uint32_t)((int32_t)v >> 28);
+    }
+    r.l[FP_N - 1] = a.l[FP_N - 1] + c;
+    BLS_SET_VB(r, BLS_VB(a));
+    return r;
 }
 
+// Partial reduction: subtracts round(a / p) * p, estimated from the top limb (a / 2^364 against p / 2^364 =
+// 106513.18; reciprocal 2^40 / that).  Any |a| <= 1024p in, |r| < 0.51p out, limbs fully carried.
+// ~50 instructions: the cheap way to stop value bounds from growing through chains of additions.
+BLS_HD fp fp_reduce(const fp& a) {
+    BLS_REQUIRE(BLS_VB(a) <= 1024, "fp_reduce bound");
+    const int64_t RECIP = 10322735;                       // round(2^40 / (p / 2^364))
+    int32_t top = (int32_t)a.l[FP_N - 1] + ((int32_t)a.l[FP_N - 2] >> 28);
+    int32_t q = (int32_t)(((int64_t)top * RECIP + (1ll << 39)) >> 40);
+    fp r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N - 1; i++) {
+        acc += (int64_t)(int32_t)a.l[i] - (int64_t)q * (int32_t)k::P[i];
+        r.l[i] = (uint32_t)acc & FP_MASK;
+        acc >>= 28;
+    }
+    acc += (int64_t)(int32_t)a.l[FP_N - 1] - (int64_t)q * (int32_t)k::P[FP_N - 1];
+    r.l[FP_N - 1] = (uint32_t)acc;
+    BLS_SET_VB(r, 1);
+    return r;
+}
+
+// a == 0 mod p for any bounded a: reduce to |r| < p, then r must be exactly 0
+BLS_HD bool fp_is_zero(const fp& a) {
+    fp r = fp_reduce(a);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) acc |= r.l[i];
+    return acc == 0;
+}
+
+BLS_HD bool fp_eq(const fp& a, const fp& b) { return fp_is_zero(fp_sub(a, b)); }
+
+// the canonical representative in [0, p), fully carried
+BLS_HD fp fp_canon(const fp& a) {
+    fp r = fp_reduce(a);                                   // |r| < p, carried, limb 13 signed
+    bool neg = (int32_t)r.l[FP_N - 1] < 0;
+    fp u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N - 1; i++) {
+        uint32_t v = r.l[i] + (neg ? k::P[i] : 0u) + c;
+        u.l[i] = v & FP_MASK;
+        c = v >> 28;
+    }
+    u.l[FP_N - 1] = r.l[FP_N - 1] + (neg ? k::P[FP_N - 1] : 0u) + c;
+    BLS_SET_VB(u, 1);
+    return u;
+}
+BLS_HD fp fp_canon_lt2p(const fp& t) { return fp_canon(t); }
+
+BLS_HD bool fp_limbs_are_zero(const fp& a) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) acc |= a.l[i];
+    return acc == 0;
+}
+BLS_HD bool fp_is_zero_any(const fp& a) { return fp_is_zero(a); }
+BLS_HD bool fp_eq_any(const fp& a, const fp& b) { return fp_eq(a, b); }
+
+// Montgomery -> plain integer, canonical limbs
+BLS_HD fp fp_from_mont(const fp& a) { return fp_canon_lt2p(fp_mul(a, fp_from_const(k::PLAIN_ONE))); }
+
+// plain integer < 2^392 given as 28-bit limbs (value bound set by the caller) -> Montgomery
 BLS_HD fp fp_to_mont(const fp& a) { return fp_mul(a, fp_from_const(k::RR)); }
 
-// a^e for a 384-bit exponent given as 12 LE limbs; fixed 4-bit window, not constant time
+// 12 x 32-bit words (little-endian integer) <-> 14 x 28-bit limbs
+BLS_HD fp fp_relimb_from32(const uint32_t (&w)[12]) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        const int bit = 28 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t v = (uint64_t)w[wi] >> sh;
+        if (sh > 4 && wi + 1 < 12) v |= (uint64_t)w[wi + 1] << (32 - sh);
+        r.l[i] = (uint32_t)v & FP_MASK;
+    }
+    BLS_SET_VB(r, 16);      // any 384-bit integer is < 16p (2^384 / p < 10)
+    return r;
+}
+BLS_HD void fp_relimb_to32(uint32_t (&w)[12], const fp& a) {   // a fully carried, < 2^384
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const int bit = 32 * j, li = bit / 28, sh = bit % 28;
+        uint64_t v = (uint64_t)a.l[li] >> sh;
+        if (li + 1 < FP_N) v |= (uint64_t)a.l[li + 1] << (28 - sh);
+        if (sh > 24 && li + 2 < FP_N) v |= (uint64_t)a.l[li + 2] << (56 - sh);
+        w[j] = (uint32_t)v;
+    }
+}
+
+// blst_fp memory image (Montgomery, R = 2^384) <-> device element (Montgomery, R = 2^392)
+BLS_HD fp fp_from_blst(const uint32_t (&w)[12]) {
+    fp v = fp_relimb_from32(w);
+    return fp_mul(v, fp_from_const(k::C400));
+}
+BLS_HD void fp_to_blst(uint32_t (&w)[12], const fp& a) {
+    fp r = fp_canon_lt2p(fp_mul(a, fp_from_const(k::C384)));   // x * 2^384 mod p
+    fp_relimb_to32(w, r);
+}
+
+// a^e for a 384-bit exponent given as 12 LE 32-bit words; fixed 4-bit window, not constant time
 // (nothing secret on this path: public keys, messages, signatures and public blinding scalars).
 BLS_HDN fp fp_pow(const fp& a, const uint32_t (&e)[12]) {
     fp tab[16];
@@ -237,22 +377,24 @@ BLS_HD fp fp_recip_sqrt_pow(const fp& a) {
     return fp_pow(a, e);
 }
 
-// 48 little-endian bytes (blst_fp memory image) <-> fp
+// 48 little-endian bytes (blst_fp memory image) <-> fp   (host-side tests and byte-addressed inputs)
 BLS_HD fp fp_load_le(const uint8_t* p) {
-    fp r;
+    uint32_t w[12];
 #pragma unroll
     for (int i = 0; i < 12; i++)
-        r.l[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
-    return r;
+        w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+    return fp_from_blst(w);
 }
 
 BLS_HD void fp_store_le(uint8_t* p, const fp& a) {
+    uint32_t w[12];
+    fp_to_blst(w, a);
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        p[4 * i] = (uint8_t)a.l[i];
-        p[4 * i + 1] = (uint8_t)(a.l[i] >> 8);
-        p[4 * i + 2] = (uint8_t)(a.l[i] >> 16);
-        p[4 * i + 3] = (uint8_t)(a.l[i] >> 24);
+        p[4 * i] = (uint8_t)w[i];
+        p[4 * i + 1] = (uint8_t)(w[i] >> 8);
+        p[4 * i + 2] = (uint8_t)(w[i] >> 16);
+        p[4 * i + 3] = (uint8_t)(w[i] >> 24);
     }
 }
 
@@ -263,20 +405,24 @@ struct fp2 {
     fp c0, c1;
 };
 
-BLS_HD fp2 fp2_from_const(const uint32_t (&c)[24]) {
+BLS_HD fp2 fp2_from_const(const uint32_t (&c)[2 * FP_N]) {
     fp2 r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < FP_N; i++) {
         r.c0.l[i] = c[i];
-        r.c1.l[i] = c[12 + i];
+        r.c1.l[i] = c[FP_N + i];
     }
+    BLS_SET_VB(r.c0, 1);
+    BLS_SET_VB(r.c1, 1);
     return r;
 }
 
 BLS_HD fp2 fp2_zero() { return fp2{fp_zero(), fp_zero()}; }
 BLS_HD fp2 fp2_one() { return fp2{fp_one(), fp_zero()}; }
 BLS_HD bool fp2_is_zero(const fp2& a) { return fp_is_zero(a.c0) & fp_is_zero(a.c1); }
+BLS_HD bool fp2_is_zero_any(const fp2& a) { return fp_is_zero_any(a.c0) & fp_is_zero_any(a.c1); }
 BLS_HD bool fp2_eq(const fp2& a, const fp2& b) { return fp_eq(a.c0, b.c0) & fp_eq(a.c1, b.c1); }
+BLS_HD bool fp2_eq_any(const fp2& a, const fp2& b) { return fp_eq_any(a.c0, b.c0) & fp_eq_any(a.c1, b.c1); }
 BLS_HD fp2 fp2_select(bool c, const fp2& a, const fp2& b) { return fp2{fp_select(c, a.c0, b.c0), fp_select(c, a.c1, b.c1)}; }
 BLS_HD fp2 fp2_add(const fp2& a, const fp2& b) { return fp2{fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
 BLS_HD fp2 fp2_sub(const fp2& a, const fp2& b) { return fp2{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
@@ -284,19 +430,20 @@ BLS_HD fp2 fp2_neg(const fp2& a) { return fp2{fp_neg(a.c0), fp_neg(a.c1)}; }
 BLS_HD fp2 fp2_dbl(const fp2& a) { return fp2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
 BLS_HD fp2 fp2_conj(const fp2& a) { return fp2{a.c0, fp_neg(a.c1)}; }
 BLS_HD fp2 fp2_mul3(const fp2& a) { return fp2_add(fp2_dbl(a), a); }
+BLS_HD fp2 fp2_reduce(const fp2& a) { return fp2{fp_reduce(a.c0), fp_reduce(a.c1)}; }
 
-// Karatsuba: 3 base multiplications
+// Karatsuba: 3 base multiplications; the operand sums skip the carry step (limbs < 2^30)
 BLS_HD fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp t0 = fp_mul(a.c0, b.c0);
     fp t1 = fp_mul(a.c1, b.c1);
-    fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    fp s = fp_mul(fp_add_nc(a.c0, a.c1), fp_add_nc(b.c0, b.c1));
     return fp2{fp_sub(t0, t1), fp_sub(fp_sub(s, t0), t1)};
 }
 
 // complex squaring: 2 base multiplications
 BLS_HD fp2 fp2_sqr(const fp2& a) {
     fp t = fp_mul(a.c0, a.c1);
-    fp c0 = fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1));
+    fp c0 = fp_mul(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1));
     return fp2{c0, fp_dbl(t)};
 }
 
@@ -317,7 +464,7 @@ BLS_HD uint32_t fp2_sgn0(const fp2& a) {
     fp x0 = fp_from_mont(a.c0);
     fp x1 = fp_from_mont(a.c1);
     uint32_t s0 = x0.l[0] & 1, s1 = x1.l[0] & 1;
-    uint32_t z0 = fp_is_zero(x0) ? 1u : 0u;
+    uint32_t z0 = fp_limbs_are_zero(x0) ? 1u : 0u;
     return s0 | (z0 & s1);
 }
 

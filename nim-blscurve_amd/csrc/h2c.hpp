@@ -10,12 +10,13 @@ namespace bls {
 
 // 64 big-endian bytes (as 16 BE words) -> Fp (Montgomery), value mod p.  hi, lo < 2^256 < p.
 BLS_HD fp fp_from_be_words16(const uint32_t* wbe) {
-    fp hi = fp_zero(), lo = fp_zero();
+    uint32_t hw[12], lw[12];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        hi.l[i] = wbe[7 - i];
-        lo.l[i] = wbe[15 - i];
+    for (int i = 0; i < 12; i++) {
+        hw[i] = i < 8 ? wbe[7 - i] : 0u;
+        lw[i] = i < 8 ? wbe[15 - i] : 0u;
     }
+    fp hi = fp_relimb_from32(hw), lo = fp_relimb_from32(lw);
     fp him = fp_mul(fp_to_mont(hi), fp_from_const(k::TWO256));
     return fp_add(him, fp_to_mont(lo));
 }
@@ -75,7 +76,7 @@ BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
     n = fp_select(is_sq, n, nz);
     fp half = fp_from_const(k::HALF);
     fp d = fp_mul(fp_add(g.c0, n), half);
-    d = fp_select(fp_is_zero(d), g.c0, d);
+    d = fp_select(fp_is_zero(d), fp_reduce(g.c0), d);
     fp t3 = fp_recip_sqrt_pow(d);
     fp x0 = fp_mul(d, t3);
     bool qr = fp_eq(fp_sqr(x0), d);
@@ -91,7 +92,7 @@ BLS_MID g2_jac sswu_g2(const fp2& u) {
     fp2 tv1 = fp2_mul(Z, fp2_sqr(u));
     fp2 tv2 = fp2_add(fp2_sqr(tv1), tv1);
     fp2 xn = fp2_mul(B, fp2_add(tv2, fp2_one()));                 // x1 numerator
-    fp2 xd = fp2_select(fp2_is_zero(tv2), fp2_from_const(k::SSWU_ZA), fp2_mul(A, fp2_neg(tv2)));
+    fp2 xd = fp2_select(fp2_is_zero_any(tv2), fp2_from_const(k::SSWU_ZA), fp2_mul(A, fp2_neg(tv2)));
     fp2 xd2 = fp2_sqr(xd);
     fp2 D = fp2_mul(xd2, xd);
     fp2 N = fp2_add(fp2_mul(fp2_add(fp2_sqr(xn), fp2_mul(A, xd2)), xn), fp2_mul(B, D));

@@ -48,24 +48,28 @@ struct dst_t {
 };
 
 // ------------------------------------------------------------------------------------------
-// SoA accessors: plane p of element i lives at base[(3p+q)*stride + i], q = 0..2 (uint4 each)
+// SoA accessors: an Fp element is 14 limbs = 4 uint4 (2 pad words); plane p of element i lives at
+// base[(4p+q)*stride + i], q = 0..3
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ fp soa_ld(const uint4* base, size_t stride, uint32_t plane, size_t i) {
     fp r;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        uint4 v = base[(size_t)(plane * 3 + q) * stride + i];
+    for (int q = 0; q < 4; q++) {
+        uint4 v = base[(size_t)(plane * 4 + q) * stride + i];
         r.l[4 * q] = v.x;
         r.l[4 * q + 1] = v.y;
-        r.l[4 * q + 2] = v.z;
-        r.l[4 * q + 3] = v.w;
+        if (q < 3) {
+            r.l[4 * q + 2] = v.z;
+            r.l[4 * q + 3] = v.w;
+        }
     }
     return r;
 }
 __device__ __forceinline__ void soa_st(uint4* base, size_t stride, uint32_t plane, size_t i, const fp& a) {
 #pragma unroll
-    for (int q = 0; q < 3; q++)
-        base[(size_t)(plane * 3 + q) * stride + i] = make_uint4(a.l[4 * q], a.l[4 * q + 1], a.l[4 * q + 2], a.l[4 * q + 3]);
+    for (int q = 0; q < 4; q++)
+        base[(size_t)(plane * 4 + q) * stride + i] =
+            q < 3 ? make_uint4(a.l[4 * q], a.l[4 * q + 1], a.l[4 * q + 2], a.l[4 * q + 3]) : make_uint4(a.l[12], a.l[13], 0u, 0u);
 }
 __device__ __forceinline__ fp2 soa_ld2(const uint4* base, size_t stride, uint32_t plane, size_t i) {
     return fp2{soa_ld(base, stride, plane, i), soa_ld(base, stride, plane + 1, i)};
@@ -91,34 +95,74 @@ __device__ __forceinline__ void soa_st_g1(uint4* base, size_t stride, size_t i, 
     soa_st(base, stride, 2, i, a.z);
 }
 
-// aligned word loads of the reference's AoS records (u64-limb structs: 8-byte aligned)
-__device__ __forceinline__ fp ld_fp_words(const uint32_t* w) {
+// Internal AoS buffers (partials, step products): FPW words per Fp (14 limbs + 2 pad), device representation.
+constexpr int FPW = 16, G1W = 3 * FPW, G2W = 6 * FPW, F12W = 12 * FPW;
+__device__ __forceinline__ fp ld_fp_int(const uint32_t* w) {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = w[i];
+    for (int i = 0; i < FP_N; i++) r.l[i] = w[i];
     return r;
 }
-__device__ __forceinline__ void st_fp_words(uint32_t* w, const fp& a) {
+__device__ __forceinline__ void st_fp_int(uint32_t* w, const fp& a) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) w[i] = a.l[i];
+    for (int i = 0; i < FP_N; i++) w[i] = a.l[i];
 }
-__device__ __forceinline__ void st_fp12_words(uint32_t* w, const fp12& a) {
+__device__ __forceinline__ g1_jac ld_g1_int(const uint32_t* w) { return g1_jac{ld_fp_int(w), ld_fp_int(w + FPW), ld_fp_int(w + 2 * FPW)}; }
+__device__ __forceinline__ void st_g1_int(uint32_t* w, const g1_jac& a) {
+    st_fp_int(w, a.x); st_fp_int(w + FPW, a.y); st_fp_int(w + 2 * FPW, a.z);
+}
+__device__ __forceinline__ g2_jac ld_g2_int(const uint32_t* w) {
+    return g2_jac{fp2{ld_fp_int(w), ld_fp_int(w + FPW)}, fp2{ld_fp_int(w + 2 * FPW), ld_fp_int(w + 3 * FPW)},
+                  fp2{ld_fp_int(w + 4 * FPW), ld_fp_int(w + 5 * FPW)}};
+}
+__device__ __forceinline__ void st_g2_int(uint32_t* w, const g2_jac& a) {
+    st_fp_int(w, a.x.c0); st_fp_int(w + FPW, a.x.c1); st_fp_int(w + 2 * FPW, a.y.c0);
+    st_fp_int(w + 3 * FPW, a.y.c1); st_fp_int(w + 4 * FPW, a.z.c0); st_fp_int(w + 5 * FPW, a.z.c1);
+}
+__device__ __forceinline__ void st_fp12_int(uint32_t* w, const fp12& a) {
     const fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        st_fp_words(w + 24 * i, c[i]->c0);
-        st_fp_words(w + 24 * i + 12, c[i]->c1);
+        st_fp_int(w + 2 * FPW * i, c[i]->c0);
+        st_fp_int(w + 2 * FPW * i + FPW, c[i]->c1);
     }
 }
-__device__ __forceinline__ fp12 ld_fp12_words(const uint32_t* w) {
+__device__ __forceinline__ fp12 ld_fp12_int(const uint32_t* w) {
     fp12 a;
     fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        c[i]->c0 = ld_fp_words(w + 24 * i);
-        c[i]->c1 = ld_fp_words(w + 24 * i + 12);
+        c[i]->c0 = ld_fp_int(w + 2 * FPW * i);
+        c[i]->c1 = ld_fp_int(w + 2 * FPW * i + FPW);
     }
     return a;
+}
+
+// The reference's memory images (blst_fp: 12 words, Montgomery R = 2^384; u64-limb structs, 8-byte aligned):
+// converted to / from the device representation with one multiplication per element.
+__device__ __forceinline__ fp ld_fp_blst(const uint32_t* w) {
+    uint32_t t[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) t[i] = w[i];
+    return fp_from_blst(t);
+}
+__device__ __forceinline__ void st_fp_blst(uint32_t* w, const fp& a) {
+    uint32_t t[12];
+    fp_to_blst(t, a);
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = t[i];
+}
+__device__ __forceinline__ g1_aff ld_g1a_blst(const uint32_t* w) { return g1_aff{ld_fp_blst(w), ld_fp_blst(w + 12)}; }
+__device__ __forceinline__ g2_aff ld_g2a_blst(const uint32_t* w) {
+    return g2_aff{fp2{ld_fp_blst(w), ld_fp_blst(w + 12)}, fp2{ld_fp_blst(w + 24), ld_fp_blst(w + 36)}};
+}
+__device__ __forceinline__ g1_jac ld_g1_blst(const uint32_t* w) { return g1_jac{ld_fp_blst(w), ld_fp_blst(w + 12), ld_fp_blst(w + 24)}; }
+__device__ __forceinline__ void st_g1_blst(uint32_t* w, const g1_jac& a) {
+    st_fp_blst(w, a.x); st_fp_blst(w + 12, a.y); st_fp_blst(w + 24, a.z);
+}
+__device__ __forceinline__ void st_g2_blst(uint32_t* w, const g2_jac& a) {
+    st_fp_blst(w, a.x.c0); st_fp_blst(w + 12, a.x.c1); st_fp_blst(w + 24, a.y.c0);
+    st_fp_blst(w + 36, a.y.c1); st_fp_blst(w + 48, a.z.c0); st_fp_blst(w + 60, a.z.c1);
 }
 
 // wave-level exchange of whole structs through DPP/bpermute shuffles
@@ -207,7 +251,7 @@ __global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
-    g1_aff pk{ld_fp_words(w), ld_fp_words(w + 12)};
+    g1_aff pk = ld_g1a_blst(w);
     if (aff_is_inf(pk)) atomicOr(flags, 1u);        // BLST_PK_IS_INFINITY -> update() false
     g1_jac q = jac_mul_u64(pk, r[i]);
     soa_st_g1(P, stride, i, q);
@@ -218,7 +262,7 @@ __global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ set
     g2_jac acc = jac_inf<fp2>();
     if (i < n) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 128);
-        g2_aff s{fp2{ld_fp_words(w), ld_fp_words(w + 12)}, fp2{ld_fp_words(w + 24), ld_fp_words(w + 36)}};
+        g2_aff s = ld_g2a_blst(w);
         acc = jac_mul_u64(s, r[i]);                 // infinity signature -> infinity (contributes nothing)
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -226,31 +270,20 @@ __global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ set
         acc = jac_add(acc, o);
     }
     if (threadIdx.x == 0) {
-        uint32_t* o = part + (size_t)blockIdx.x * 72;
-        st_fp_words(o, acc.x.c0); st_fp_words(o + 12, acc.x.c1);
-        st_fp_words(o + 24, acc.y.c0); st_fp_words(o + 36, acc.y.c1);
-        st_fp_words(o + 48, acc.z.c0); st_fp_words(o + 60, acc.z.c1);
+        st_g2_int(part + (size_t)blockIdx.x * G2W, acc);
     }
-}
-
-__device__ __forceinline__ g2_jac ld_g2_words(const uint32_t* o) {
-    return g2_jac{fp2{ld_fp_words(o), ld_fp_words(o + 12)}, fp2{ld_fp_words(o + 24), ld_fp_words(o + 36)},
-                  fp2{ld_fp_words(o + 48), ld_fp_words(o + 60)}};
 }
 
 // level 1 of the partial-sum reduction: block b folds partials b, b+gridDim.x, ... -> part2[b]
 __global__ void __launch_bounds__(WAVE) k_sigsum1(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ part2) {
     g2_jac acc = jac_inf<fp2>();
-    for (uint32_t j = blockIdx.x * WAVE + threadIdx.x; j < nparts; j += WAVE * gridDim.x) acc = jac_add(acc, ld_g2_words(part + (size_t)j * 72));
+    for (uint32_t j = blockIdx.x * WAVE + threadIdx.x; j < nparts; j += WAVE * gridDim.x) acc = jac_add(acc, ld_g2_int(part + (size_t)j * G2W));
     for (int d = 32; d >= 1; d >>= 1) {
         g2_jac o = shfl_down_struct(acc, d);
         acc = jac_add(acc, o);
     }
     if (threadIdx.x == 0) {
-        uint32_t* o = part2 + (size_t)blockIdx.x * 72;
-        st_fp_words(o, acc.x.c0); st_fp_words(o + 12, acc.x.c1);
-        st_fp_words(o + 24, acc.y.c0); st_fp_words(o + 36, acc.y.c1);
-        st_fp_words(o + 48, acc.z.c0); st_fp_words(o + 60, acc.z.c1);
+        st_g2_int(part2 + (size_t)blockIdx.x * G2W, acc);
     }
 }
 
@@ -258,7 +291,7 @@ __global__ void __launch_bounds__(WAVE) k_sigsum1(const uint32_t* __restrict__ p
 __global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ part, uint32_t nparts, uint4* __restrict__ H, uint4* __restrict__ P,
                                                  size_t stride, size_t slot, uint32_t* __restrict__ agg_out) {
     g2_jac acc = jac_inf<fp2>();
-    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = jac_add(acc, ld_g2_words(part + (size_t)j * 72));
+    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = jac_add(acc, ld_g2_int(part + (size_t)j * G2W));
     for (int d = 32; d >= 1; d >>= 1) {
         g2_jac o = shfl_down_struct(acc, d);
         acc = jac_add(acc, o);
@@ -267,9 +300,7 @@ __global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ pa
         soa_st_g2(H, stride, slot, acc);
         g1_jac ng{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()};
         soa_st_g1(P, stride, slot, ng);
-        st_fp_words(agg_out, acc.x.c0); st_fp_words(agg_out + 12, acc.x.c1);
-        st_fp_words(agg_out + 24, acc.y.c0); st_fp_words(agg_out + 36, acc.y.c1);
-        st_fp_words(agg_out + 48, acc.z.c0); st_fp_words(agg_out + 60, acc.z.c1);
+        st_g2_blst(agg_out, acc);
     }
 }
 
@@ -282,7 +313,7 @@ __global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, con
     g1_jac p = soa_ld_g1(P, stride, i);
     g2_jac q = soa_ld_g2(H, stride, i);
     miller_lines(p, q, [&](int s, const line_t& l) {
-        uint4* b = lines + (size_t)s * 18 * stride;
+        uint4* b = lines + (size_t)s * 24 * stride;
         soa_st2(b, stride, 0, i, l.l0);
         soa_st2(b, stride, 2, i, l.l1);
         soa_st2(b, stride, 4, i, l.l2);
@@ -293,7 +324,7 @@ __global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, con
 __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lines, uint32_t npairs, size_t stride, uint32_t m,
                                                    uint32_t* __restrict__ part, uint32_t nblk) {
     uint32_t s = blockIdx.x, b = blockIdx.y;
-    const uint4* base = lines + (size_t)s * 18 * stride;
+    const uint4* base = lines + (size_t)s * 24 * stride;
     size_t first = (size_t)b * WAVE * m;
     fp12 f = fp12_one();
     bool have = false;
@@ -309,7 +340,7 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
         fp12 o = shfl_down_struct(f, d);
         f = fp12_mul(f, o);
     }
-    if (threadIdx.x == 0) st_fp12_words(part + ((size_t)s * nblk + b) * 144, f);
+    if (threadIdx.x == 0) st_fp12_int(part + ((size_t)s * nblk + b) * F12W, f);
 }
 
 // per step: product of the nblk range partials, times the line of the extra pair `xpair`
@@ -319,18 +350,18 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
     uint32_t s = blockIdx.x;
     fp12 f = fp12_one();
     if (threadIdx.x == 0 && xpair != 0xffffffffu) {
-        const uint4* base = lines + (size_t)s * 18 * stride;
+        const uint4* base = lines + (size_t)s * 24 * stride;
         f = fp12_from_line(line_t{soa_ld2(base, stride, 0, xpair), soa_ld2(base, stride, 2, xpair), soa_ld2(base, stride, 4, xpair)});
     }
     for (uint32_t j = threadIdx.x; j < nblk; j += WAVE) {
-        fp12 o = ld_fp12_words(part + ((size_t)s * nblk + j) * 144);
+        fp12 o = ld_fp12_int(part + ((size_t)s * nblk + j) * F12W);
         f = fp12_mul(f, o);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         fp12 o = shfl_down_struct(f, d);
         f = fp12_mul(f, o);
     }
-    if (threadIdx.x == 0) st_fp12_words(L + (size_t)s * 144, f);
+    if (threadIdx.x == 0) st_fp12_int(L + (size_t)s * F12W, f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -368,6 +399,7 @@ __device__ __noinline__ void c12_mul(c12_lds& S, int d, int a, int b) {
             fp wr = comp ? fp_add(P.c0, P.c1) : fp_sub(P.c0, P.c1);      // (x0 + x1 u)(1 + u)
             acc = fp_add(acc, fp_select(wrap, wr, lo));
         }
+        acc = fp_reduce(acc);          // keeps the stored coefficients at |v| < p: bounds never accumulate
         if (comp) S.r[d][kk].c1 = acc; else S.r[d][kk].c0 = acc;
     }
     __syncthreads();
@@ -392,17 +424,22 @@ __device__ __forceinline__ void c12_frob2(c12_lds& S, int d, int a) {
     if (lane < 6) S.r[d][lane] = fp2_mul_fp(S.r[a][lane], S.frob2[lane]);
     __syncthreads();
 }
-__device__ __forceinline__ void c12_load(c12_lds& S, int d, const uint32_t* g) {   // blst_fp12 image
+__device__ __forceinline__ void c12_load(c12_lds& S, int d, const uint32_t* g) {   // blst_fp12 image (576 B)
     int lane = threadIdx.x;
-    if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_words(g + 24 * lane), ld_fp_words(g + 24 * lane + 12)};
+    if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_blst(g + 24 * lane), ld_fp_blst(g + 24 * lane + 12)};
+    __syncthreads();
+}
+__device__ __forceinline__ void c12_load_int(c12_lds& S, int d, const uint32_t* g) {   // internal Fp12 (F12W words)
+    int lane = threadIdx.x;
+    if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_int(g + 2 * FPW * lane), ld_fp_int(g + 2 * FPW * lane + FPW)};
     __syncthreads();
 }
 __device__ __forceinline__ void c12_store(const c12_lds& S, int a, uint32_t* g) {
     int lane = threadIdx.x;
     if (lane < 6) {
         const fp2& v = S.r[a][c12_flat_of_tower(lane)];
-        st_fp_words(g + 24 * lane, v.c0);
-        st_fp_words(g + 24 * lane + 12, v.c1);
+        st_fp_blst(g + 24 * lane, v.c0);
+        st_fp_blst(g + 24 * lane + 12, v.c1);
     }
     __syncthreads();
 }
@@ -451,10 +488,10 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         int s = 0;
         for (int bit = 62; bit >= 0; bit--) {
             c12_mul(S, F, F, F);
-            c12_load(S, X1, L + (size_t)(s++) * 144);
+            c12_load_int(S, X1, L + (size_t)(s++) * F12W);
             c12_mul(S, F, F, X1);
             if ((k::X_ABS >> bit) & 1) {
-                c12_load(S, X1, L + (size_t)(s++) * 144);
+                c12_load_int(S, X1, L + (size_t)(s++) * F12W);
                 c12_mul(S, F, F, X1);
             }
         }
@@ -514,7 +551,7 @@ __global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts
         uint32_t i = lane0 + j * strideL;
         if (i < n) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + (size_t)i * 96);
-            g1_aff q{ld_fp_words(w), ld_fp_words(w + 12)};
+            g1_aff q = ld_g1a_blst(w);
             acc = jac_add_aff(acc, q);
         }
     }
@@ -523,32 +560,30 @@ __global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts
         acc = jac_add(acc, o);
     }
     if (threadIdx.x == 0) {
-        uint32_t* o = part + (size_t)blockIdx.x * 36;
-        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+        st_g1_int(part + (size_t)blockIdx.x * G1W, acc);
     }
 }
 __global__ void __launch_bounds__(WAVE) k_g1_sum2(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ out) {
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) {
-        const uint32_t* o = part + (size_t)j * 36;
-        acc = jac_add(acc, g1_jac{ld_fp_words(o), ld_fp_words(o + 12), ld_fp_words(o + 24)});
+        acc = jac_add(acc, ld_g1_int(part + (size_t)j * G1W));
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
         acc = jac_add(acc, o);
     }
-    if (threadIdx.x == 0) { st_fp_words(out, acc.x); st_fp_words(out + 12, acc.y); st_fp_words(out + 24, acc.z); }
+    if (threadIdx.x == 0) st_g1_blst(out, acc);        // blst_p1 image
 }
 // pairs of coreVerifyNoGroupCheck (core :269-297): slot 0 = (aggregate pk, H(msg)) [H written by k_hash_one],
 // slot 1 = (-G1, signature).  Aggregate at infinity -> BLST_PK_IS_INFINITY flag.
 __global__ void k_fav_setup(const uint32_t* __restrict__ agg, const uint32_t* __restrict__ sig, uint4* __restrict__ H, uint4* __restrict__ P,
                             size_t stride, uint32_t* __restrict__ flags) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g1_jac a{ld_fp_words(agg), ld_fp_words(agg + 12), ld_fp_words(agg + 24)};
+    g1_jac a = ld_g1_blst(agg);
     if (jac_is_inf(a)) atomicOr(flags, 1u);
     soa_st_g1(P, stride, 0, a);
     soa_st_g1(P, stride, 1, g1_jac{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()});
-    g2_aff sg{fp2{ld_fp_words(sig), ld_fp_words(sig + 12)}, fp2{ld_fp_words(sig + 24), ld_fp_words(sig + 36)}};
+    g2_aff sg = ld_g2a_blst(sig);
     soa_st_g2(H, stride, 1, jac_from_aff(sg));
 }
 
@@ -617,8 +652,17 @@ __global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict_
         sorted[(size_t)w * n + pos] = i;
     }
 }
+// points are converted once from the blst image to the device representation (2 multiplications per
+// point instead of 2 per bucket addition): internal AoS, 2 x FPW words per point
+__global__ void __launch_bounds__(WAVE) k_msm_convert(const uint8_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ pts_int) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    g1_aff q = ld_g1a_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * 96));
+    st_fp_int(pts_int + (size_t)i * 2 * FPW, q.x);
+    st_fp_int(pts_int + (size_t)i * 2 * FPW + FPW, q.y);
+}
 // lane per (window, bucket); `order` (optional) lists the buckets so that a wave's lanes have similar counts
-__global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint8_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
                                                      const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t c,
                                                      uint32_t total, uint4* __restrict__ buckets) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
@@ -628,8 +672,8 @@ __global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint8_t* __restrict__
     const uint32_t* srt = sorted + (size_t)w * n + off;
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t* pw = reinterpret_cast<const uint32_t*>(pts + (size_t)srt[j] * 96);
-        g1_aff q{ld_fp_words(pw), ld_fp_words(pw + 12)};
+        const uint32_t* pw = pts + (size_t)srt[j] * (2 * FPW);
+        g1_aff q{ld_fp_int(pw), ld_fp_int(pw + FPW)};
         acc = jac_add_aff(acc, q);
     }
     soa_st_g1(buckets, total, g, acc);
@@ -716,8 +760,7 @@ __global__ void __launch_bounds__(WAVE) k_msm_winpart(const uint4* __restrict__ 
         acc = jac_add(acc, o);
     }
     if (threadIdx.x == 0) {
-        uint32_t* o = part + ((size_t)w * nsplit + sp) * 36;
-        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+        st_g1_int(part + ((size_t)w * nsplit + sp) * G1W, acc);
     }
 }
 // one wave per window: R_w = sum of its nsplit partial sums, then 2^(off_w) * R_w
@@ -725,8 +768,7 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
     uint32_t w = blockIdx.x;
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) {
-        const uint32_t* o = part + ((size_t)w * nsplit + j) * 36;
-        acc = jac_add(acc, g1_jac{ld_fp_words(o), ld_fp_words(o + 12), ld_fp_words(o + 24)});
+        acc = jac_add(acc, ld_g1_int(part + ((size_t)w * nsplit + j) * G1W));
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
@@ -735,8 +777,7 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
     if (threadIdx.x == 0) {
         uint32_t sh = msm_win_off(W, w);
         for (uint32_t i = 0; i < sh; i++) acc = jac_dbl(acc);
-        uint32_t* o = winout + (size_t)w * 36;
-        st_fp_words(o, acc.x); st_fp_words(o + 12, acc.y); st_fp_words(o + 24, acc.z);
+        st_g1_int(winout + (size_t)w * G1W, acc);
     }
 }
 
@@ -745,17 +786,13 @@ __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     g2_jac a = soa_ld_g2(H, stride, i);
-    uint32_t* o = out + (size_t)i * 72;
-    st_fp_words(o, a.x.c0); st_fp_words(o + 12, a.x.c1);
-    st_fp_words(o + 24, a.y.c0); st_fp_words(o + 36, a.y.c1);
-    st_fp_words(o + 48, a.z.c0); st_fp_words(o + 60, a.z.c1);
+    st_g2_blst(out + (size_t)i * 72, a);
 }
 __global__ void k_export_g1(const uint4* __restrict__ P, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     g1_jac a = soa_ld_g1(P, stride, i);
-    uint32_t* o = out + (size_t)i * 36;
-    st_fp_words(o, a.x); st_fp_words(o + 12, a.y); st_fp_words(o + 24, a.z);
+    st_g1_blst(out + (size_t)i * 36, a);
 }
 
 }  // namespace
@@ -768,11 +805,12 @@ struct msm_ws {
     uint32_t cap_total = 0, cap_seg = 0;
     uint8_t* d_pts = nullptr;
     uint8_t* d_sc = nullptr;
+    uint32_t* pts_int = nullptr;
     uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr;
     uint4 *buckets = nullptr, *segout = nullptr;
 };
 static void msm_free(msm_ws* m) {
-    void* b[] = {m->d_pts, m->d_sc, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout};
+    void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout};
     for (void* x : b)
         if (x) (void)hipFree(x);
     *m = msm_ws();
@@ -864,19 +902,19 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_sets, max_sets * 320);
     ALLOC(c->d_rnd, 32);
     ALLOC(c->d_r, c->stride * 8);
-    ALLOC(c->d_H, c->stride * 288);
-    ALLOC(c->d_P, c->stride * 144);
-    ALLOC(c->d_lines, c->stride * 288 * (size_t)N_LINES);
-    ALLOC(c->d_spart, (nwaves + 16) * 288);
+    ALLOC(c->d_H, c->stride * 6 * 64);
+    ALLOC(c->d_P, c->stride * 3 * 64);
+    ALLOC(c->d_lines, c->stride * 6 * 64 * (size_t)N_LINES);
+    ALLOC(c->d_spart, (nwaves + 16) * G2W * 4);
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
     ALLOC(c->d_msg, 4096 + 192);
-    ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * 576);
-    ALLOC(c->d_L, (size_t)N_LINES * 576);
+    ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * F12W * 4);
+    ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_flags, 16);
-    ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * 144);
+    ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -926,7 +964,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[3], st));
     k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_spart);
     if (nb > 64) {          // two-level fold: 16 waves, then one
-        uint32_t* part2 = c->d_spart + (size_t)nb * 72;
+        uint32_t* part2 = c->d_spart + (size_t)nb * G2W;
         k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
         k_sigsum<<<1, WAVE, 0, st>>>(part2, 16, c->d_H, c->d_P, c->stride, n, c->d_agg);
     } else {
@@ -1208,15 +1246,16 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
     } while (0)
     MALLOC(m->d_pts, cn * 96);
     MALLOC(m->d_sc, cn * 32);
+    MALLOC(m->pts_int, cn * 2 * FPW * 4);
     MALLOC(m->hist, (size_t)ct * 4);
     MALLOC(m->offs, (size_t)ct * 4);
     MALLOC(m->cursor, (size_t)ct * 4);
     MALLOC(m->order, (size_t)ct * 4);
     MALLOC(m->chist, 256 * 4);
     MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 64 windows (nbits 256 at c = 4)
-    MALLOC(m->buckets, (size_t)ct * 144);
-    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 144);
-    MALLOC(m->winout, 64 * 144);
+    MALLOC(m->buckets, (size_t)ct * 3 * 64);
+    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 3 * 64);
+    MALLOC(m->winout, 64 * G1W * 4);
     MALLOC(m->out, 144);
 #undef MALLOC
     m->cap_n = cn;
@@ -1249,6 +1288,7 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
     HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
+    k_msm_convert<<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
     k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->hist);
     k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
     k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->cursor, m->sorted);
@@ -1257,7 +1297,7 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
     k_msm_order_scatter<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_msm_bucket<<<nbt, WAVE, 0, st>>>(pts, m->sorted, m->offs, m->hist, m->order, n, cb, total, m->buckets);
+    k_msm_bucket<<<nbt, WAVE, 0, st>>>(m->pts_int, m->sorted, m->offs, m->hist, m->order, n, cb, total, m->buckets);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_msm_segred<<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, cb, MSM_SEG, nseg, m->segout);
     HIPCHK(hipEventRecord(c->ev[3], st));

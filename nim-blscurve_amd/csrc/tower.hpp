@@ -18,6 +18,9 @@ BLS_HD fp6 fp6_sub(const fp6& a, const fp6& b) { return fp6{fp2_sub(a.a0, b.a0),
 BLS_HD fp6 fp6_neg(const fp6& a) { return fp6{fp2_neg(a.a0), fp2_neg(a.a1), fp2_neg(a.a2)}; }
 BLS_HD fp6 fp6_dbl(const fp6& a) { return fp6{fp2_dbl(a.a0), fp2_dbl(a.a1), fp2_dbl(a.a2)}; }
 BLS_HD fp6 fp6_mul_by_v(const fp6& a) { return fp6{fp2_mul_xi(a.a2), a.a0, a.a1}; }
+// partial reduction of every coefficient (|v| < 0.51p): Fp12-level results are stored reduced so that value
+// bounds never accumulate across the Karatsuba layers
+BLS_HD fp6 fp6_reduce(const fp6& a) { return fp6{fp2_reduce(a.a0), fp2_reduce(a.a1), fp2_reduce(a.a2)}; }
 
 // 6 fp2 multiplications
 BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
@@ -53,16 +56,16 @@ BLS_HDN fp6 fp6_inv(const fp6& a) {
     fp2 c1 = fp2_sub(fp2_mul_xi(fp2_sqr(a.a2)), fp2_mul(a.a0, a.a1));
     fp2 c2 = fp2_sub(fp2_sqr(a.a1), fp2_mul(a.a0, a.a2));
     fp2 t = fp2_add(fp2_mul(a.a0, c0), fp2_mul_xi(fp2_add(fp2_mul(a.a2, c1), fp2_mul(a.a1, c2))));
-    fp2 ti = fp2_inv(t);
-    return fp6{fp2_mul(c0, ti), fp2_mul(c1, ti), fp2_mul(c2, ti)};
+    fp2 ti = fp2_inv(fp2_reduce(t));
+    return fp6_reduce(fp6{fp2_mul(fp2_reduce(c0), ti), fp2_mul(fp2_reduce(c1), ti), fp2_mul(fp2_reduce(c2), ti)});
 }
 
 BLS_HD fp12 fp12_one() { return fp12{fp6{fp2_one(), fp2_zero(), fp2_zero()}, fp6_zero()}; }
 BLS_HD fp12 fp12_conj(const fp12& a) { return fp12{a.c0, fp6_neg(a.c1)}; }
 
 BLS_HD bool fp12_is_one(const fp12& a) {
-    return fp2_eq(a.c0.a0, fp2_one()) & fp2_is_zero(a.c0.a1) & fp2_is_zero(a.c0.a2) & fp2_is_zero(a.c1.a0) &
-           fp2_is_zero(a.c1.a1) & fp2_is_zero(a.c1.a2);
+    return fp2_eq_any(a.c0.a0, fp2_one()) & fp2_is_zero_any(a.c0.a1) & fp2_is_zero_any(a.c0.a2) & fp2_is_zero_any(a.c1.a0) &
+           fp2_is_zero_any(a.c1.a1) & fp2_is_zero_any(a.c1.a2);
 }
 
 // 3 fp6 multiplications (54 fp mul)
@@ -71,7 +74,7 @@ BLS_HDN fp12 fp12_mul(const fp12& a, const fp12& b) {
     fp6 t1 = fp6_mul(a.c1, b.c1);
     fp6 c1 = fp6_sub(fp6_sub(fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1)), t0), t1);
     fp6 c0 = fp6_add(t0, fp6_mul_by_v(t1));
-    return fp12{c0, c1};
+    return fp12{fp6_reduce(c0), fp6_reduce(c1)};
 }
 
 // complex squaring: 2 fp6 multiplications
@@ -79,7 +82,7 @@ BLS_HDN fp12 fp12_sqr(const fp12& a) {
     fp6 t = fp6_mul(a.c0, a.c1);
     fp6 s = fp6_mul(fp6_add(a.c0, a.c1), fp6_add(a.c0, fp6_mul_by_v(a.c1)));
     fp6 c0 = fp6_sub(fp6_sub(s, t), fp6_mul_by_v(t));
-    return fp12{c0, fp6_dbl(t)};
+    return fp12{fp6_reduce(c0), fp6_reduce(fp6_dbl(t))};
 }
 
 // Miller-loop line  l = l0 + l1*v + l2*v*w  (coefficients at tower slots c0.a0, c0.a1, c1.a1)
@@ -94,7 +97,7 @@ BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     fp6 s = fp6_mul_by_01(fp6_add(f.c0, f.c1), l.l0, fp2_add(l.l1, l.l2));
     fp6 c1 = fp6_sub(fp6_sub(s, t0), t1);
     fp6 c0 = fp6_add(t0, fp6_mul_by_v(t1));
-    return fp12{c0, c1};
+    return fp12{fp6_reduce(c0), fp6_reduce(c1)};
 }
 
 BLS_HD fp12 fp12_from_line(const line_t& l) {
@@ -102,9 +105,9 @@ BLS_HD fp12 fp12_from_line(const line_t& l) {
 }
 
 BLS_HDN fp12 fp12_inv(const fp12& a) {
-    fp6 d = fp6_sub(fp6_mul(a.c0, a.c0), fp6_mul_by_v(fp6_mul(a.c1, a.c1)));
+    fp6 d = fp6_reduce(fp6_sub(fp6_mul(a.c0, a.c0), fp6_mul_by_v(fp6_mul(a.c1, a.c1))));
     fp6 di = fp6_inv(d);
-    return fp12{fp6_mul(a.c0, di), fp6_neg(fp6_mul(a.c1, di))};
+    return fp12{fp6_reduce(fp6_mul(a.c0, di)), fp6_reduce(fp6_neg(fp6_mul(a.c1, di)))};
 }
 
 // a^p.  Flat basis w^i <-> tower: w^0,2,4 = c0.a0,a1,a2 ; w^1,3,5 = c1.a0,a1,a2

@@ -4,5 +4,5 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p _build
 if [ ! -f _build/libemu.so ] || [ emu.hip -nt _build/libemu.so ] || [ -n "$(find ../../nim-blscurve_amd/csrc -name '*.hpp' -newer _build/libemu.so)" ]; then
-  hipcc -O2 -std=c++17 --offload-host-only -fPIC -shared -I ../../nim-blscurve_amd/csrc emu.hip -o _build/libemu.so
+  hipcc -O2 -std=c++17 --offload-host-only -DBLS_TRACK_BOUNDS -g -rdynamic -fPIC -shared -I ../../nim-blscurve_amd/csrc emu.hip -o _build/libemu.so
 fi
