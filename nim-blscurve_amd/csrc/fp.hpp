@@ -14,7 +14,7 @@
 // bounded in magnitude by a small multiple of p (never reduced into [0, p) except by fp_canon).
 // Additions and subtractions are limb-wise plus ONE parallel carry step (no sequential carry chain, no
 // conditional subtraction, no bias constant), so value bounds grow additively.  fp_mul accepts limbs of
-// magnitude < 2^30 and value bounds whose product is <= 2048 p^2, and returns a value in (-2p, 2p).
+// magnitude < 2^29 + 2^20 (a carry-less sum of two elements) and value bounds whose product is <= 2048 p^2, and returns a value in (-2p, 2p).
 // The host test build (-DBLS_TRACK_BOUNDS, tests/host_emu) carries a worst-case magnitude bound with
 // every element and asserts these preconditions on every operation, independent of the data.
 //
@@ -160,7 +160,8 @@ BLS_HD fp fp_neg(const fp& a) {
 BLS_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 
 // Montgomery product a*b*2^-392 mod p: product scanning, ONE signed 64-bit accumulator, 392 multiply-adds
-// (v_mad_i64_i32).  Column bound: 14 * (2^30)^2 + 14 * 2^56 + carry < 2^63.  m_k in [0, 2^28) makes the low 28
+// (v_mad_i64_i32).  Operand limbs are at most limb-wise sums of two semi-normalised values (|l| < 2^29 + 16):
+// column bound 14 * (2^29.01)^2 + 14 * 2^56 + carry < 2^62.  m_k in [0, 2^28) makes the low 28
 // bits of the column vanish; the arithmetic shift is then an exact division.  Result in (-2p, 2p).
 BLS_HD fp fp_mul_core(const fp& a, const fp& b) {
     int64_t acc = 0;
@@ -190,6 +191,36 @@ BLS_HD fp fp_mul_core(const fp& a, const fp& b) {
     return r;
 }
 
+// Montgomery square: the 91 off-diagonal products are formed once against the doubled operand, so the
+// operand half costs 105 multiply-adds instead of 196 (301 in all).  Same bounds as fp_mul_core.
+BLS_HD fp fp_sqr_core(const fp& a) {
+    int64_t acc = 0;
+    int32_t m[FP_N], a2[FP_N];
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) a2[i] = (int32_t)a.l[i] * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2 * FP_N - 1; kk++) {
+#pragma unroll
+        for (int i = (kk < FP_N ? 0 : kk - FP_N + 1); 2 * i < kk; i++) acc += (int64_t)a2[i] * (int32_t)a.l[kk - i];
+        if ((kk & 1) == 0) acc += (int64_t)(int32_t)a.l[kk / 2] * (int32_t)a.l[kk / 2];
+        if (kk < FP_N) {
+#pragma unroll
+            for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+            m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
+            acc += (int64_t)m[kk] * (int32_t)k::P[0];
+        } else {
+#pragma unroll
+            for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+            r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
+        }
+        acc >>= 28;
+    }
+    r.l[FP_N - 1] = (uint32_t)acc;
+    BLS_SET_VB(r, 2);
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // The multiplier body (~500 instructions) is shared by every caller so that hot loops fit the 64 KB
 // instruction cache.  Operands travel in VGPRs: 28 scalar parameters map to v0..v27 and the result
@@ -202,6 +233,14 @@ __device__ __noinline__ fp fp_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, ui
     fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}};
     return fp_mul_core(a, b);
 }
+__device__ __noinline__ fp fp_sqr_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                       uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13) {
+    fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+    return fp_sqr_core(a);
+}
+__device__ __forceinline__ fp fp_sqr(const fp& a) {
+    return fp_sqr_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13]);
+}
 __device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
     return fp_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13],
                        b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13]);
@@ -210,16 +249,25 @@ __device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
 __host__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
 #if defined(BLS_TRACK_BOUNDS)
     BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(b) <= 2048, "fp_mul value bounds");
+    const int64_t LIM = (1ll << 29) + (1ll << 20);     // limb-wise sum of two semi-normalised values, not three
     for (int i = 0; i < FP_N; i++) {
         int64_t x = (int32_t)a.l[i], y = (int32_t)b.l[i];
-        BLS_REQUIRE(x > -(1ll << 30) && x < (1ll << 30) && y > -(1ll << 30) && y < (1ll << 30), "fp_mul limb bound");
+        BLS_REQUIRE(x > -LIM && x < LIM && y > -LIM && y < LIM, "fp_mul limb bound");
     }
 #endif
     return fp_mul_core(a, b);
 }
+__host__ __noinline__ inline fp fp_sqr(const fp& a) {
+#if defined(BLS_TRACK_BOUNDS)
+    BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(a) <= 2048, "fp_sqr value bounds");
+    for (int i = 0; i < FP_N; i++) {
+        int64_t x = (int32_t)a.l[i];
+        BLS_REQUIRE(x > -(1ll << 29) - (1ll << 20) && x < (1ll << 29) + (1ll << 20), "fp_sqr limb bound");
+    }
 #endif
-
-BLS_HD fp fp_sqr(const fp& a) { return fp_mul(a, a); }
+    return fp_sqr_core(a);
+}
+#endif
 
 // a * small constant via additions
 BLS_HD fp fp_mul3(const fp& a) { return fp_add(fp_dbl(a), a); }
