@@ -374,17 +374,48 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
 constexpr int C12_NREG = 8;
 struct c12_lds {
     fp2 r[C12_NREG][6];
-    fp2 prod[36];
+    fp prod[108];        // Karatsuba triples (t0, t1, s) of the 36 (or 21) coefficient pairs
     fp2 frob[6];
     fp frob2[6];
 };
 __device__ __forceinline__ int c12_flat_of_tower(int t) { return t < 3 ? 2 * t : 2 * (t - 3) + 1; }
 
+// One Fp product of the Karatsuba triple of the coefficient pair (x, y): kind 0: x.c0*y.c0, 1: x.c1*y.c1,
+// 2: (x.c0 + x.c1)(y.c0 + y.c1).
+BLS_HD fp c12_triple(const fp2& x, const fp2& y, int kind) {
+    fp u = kind == 0 ? x.c0 : (kind == 1 ? x.c1 : fp_add_nc(x.c0, x.c1));
+    fp v = kind == 0 ? y.c0 : (kind == 1 ? y.c1 : fp_add_nc(y.c0, y.c1));
+    return fp_mul(u, v);
+}
+// acc += coef * x limb-wise (no carry), coef in {-4..4}
+BLS_HD void fp_axpy_nc(fp& acc, const fp& x, int coef) {
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) acc.l[i] += (uint32_t)(coef * (int32_t)x.l[i]);
+}
+// Adds coefficient `comp` of mult * (Fp2 product given by its Karatsuba triple t = (t0, t1, s)), times
+// xi = 1 + u for wrapped terms, to acc, then one carry step:
+//   plain:   re = t0 - t1        im = s - t0 - t1
+//   wrapped: re - im = 2 t0 - s  re + im = s - 2 t1
+// At most 6 limb units of 2^28 are added to a semi-normalised accumulator: |limbs| < 2^31 before the carry.
+BLS_HD void c12_accumulate(fp& acc, const fp* t, int comp, bool wrap, int mult) {
+    int c0 = comp ? (wrap ? 0 : -1) : (wrap ? 2 : 1);
+    int c1 = comp ? (wrap ? -2 : -1) : (wrap ? 0 : -1);
+    int cs = comp ? 1 : (wrap ? -1 : 0);
+    fp_axpy_nc(acc, t[0], c0 * mult);
+    fp_axpy_nc(acc, t[1], c1 * mult);
+    fp_axpy_nc(acc, t[2], cs * mult);
+    fp_carry_step(acc.l);
+}
+
+// d = a * b.  108 Fp products in two rounds over 54 lanes, then 12 lanes x one 6-term column sum.
 __device__ __noinline__ void c12_mul(c12_lds& S, int d, int a, int b) {
     int lane = threadIdx.x;
-    if (lane < 36) {
-        int i = lane / 6, j = lane % 6;
-        S.prod[lane] = fp2_mul(S.r[a][i], S.r[b][j]);
+    if (lane < 54) {
+#pragma unroll 1
+        for (int rnd = 0; rnd < 2; rnd++) {
+            int q = lane + 54 * rnd, pr = q / 3, kind = q % 3;
+            S.prod[q] = c12_triple(S.r[a][pr / 6], S.r[b][pr % 6], kind);
+        }
     }
     __syncthreads();
     if (lane < 12) {
@@ -394,12 +425,37 @@ __device__ __noinline__ void c12_mul(c12_lds& S, int d, int a, int b) {
             int j = kk - i;
             bool wrap = j < 0;
             if (wrap) j += 6;
-            const fp2& P = S.prod[i * 6 + j];
-            fp lo = comp ? P.c1 : P.c0;
-            fp wr = comp ? fp_add(P.c0, P.c1) : fp_sub(P.c0, P.c1);      // (x0 + x1 u)(1 + u)
-            acc = fp_add(acc, fp_select(wrap, wr, lo));
+            c12_accumulate(acc, &S.prod[3 * (i * 6 + j)], comp, wrap, 1);
         }
         acc = fp_reduce(acc);          // keeps the stored coefficients at |v| < p: bounds never accumulate
+        if (comp) S.r[d][kk].c1 = acc; else S.r[d][kk].c0 = acc;
+    }
+    __syncthreads();
+}
+// d = a^2.  Only the 21 pairs i <= j are formed: 63 Fp products, ONE round over 63 lanes.
+__device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
+    int lane = threadIdx.x;
+    if (lane < 63) {
+        int pr = lane / 3, kind = lane % 3;
+        // pair index -> (i, j), i <= j, enumerated row by row: i = 0: j = 0..5 (6), i = 1: 5, ...
+        int i = 0, base = 0;
+        while (pr >= base + (6 - i)) { base += 6 - i; i++; }
+        int j = i + (pr - base);
+        S.prod[lane] = c12_triple(S.r[a][i], S.r[a][j], kind);
+    }
+    __syncthreads();
+    if (lane < 12) {
+        int kk = lane >> 1, comp = lane & 1;
+        fp acc = fp_zero();
+        for (int i = 0; i < 6; i++) {
+            int j = kk - i;
+            bool wrap = j < 0;
+            if (wrap) j += 6;
+            if (i > j) continue;                               // (j, i) already counted, doubled
+            int pr = i * 6 - (i * (i - 1)) / 2 + (j - i);      // index of the pair (i, j) in the i <= j enumeration
+            c12_accumulate(acc, &S.prod[3 * pr], comp, wrap, i == j ? 1 : 2);
+        }
+        acc = fp_reduce(acc);
         if (comp) S.r[d][kk].c1 = acc; else S.r[d][kk].c0 = acc;
     }
     __syncthreads();
@@ -452,7 +508,7 @@ __device__ __forceinline__ void c12_set_one(c12_lds& S, int d) {
 __device__ __noinline__ void c12_cyc_exp_x(c12_lds& S, int d, int a, int tmp) {
     c12_copy(S, tmp, a);
     for (int bit = 62; bit >= 0; bit--) {
-        c12_mul(S, tmp, tmp, tmp);
+        c12_sqr(S, tmp, tmp);
         if ((k::X_ABS >> bit) & 1) c12_mul(S, tmp, tmp, a);
     }
     c12_conj(S, d, tmp);
@@ -487,7 +543,7 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         c12_set_one(S, F);
         int s = 0;
         for (int bit = 62; bit >= 0; bit--) {
-            c12_mul(S, F, F, F);
+            c12_sqr(S, F, F);
             c12_load_int(S, X1, L + (size_t)(s++) * F12W);
             c12_mul(S, F, F, X1);
             if ((k::X_ABS >> bit) & 1) {
@@ -526,7 +582,7 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         c12_mul(S, C, X2, X1);
         c12_conj(S, X1, B);
         c12_mul(S, C, C, X1);                   // c = b^(x^2+p^2-1)
-        c12_mul(S, X1, T, T);
+        c12_sqr(S, X1, T);
         c12_mul(S, X1, X1, T);                  // t^3
         c12_mul(S, C, C, X1);
         c12_store(S, C, gt_out);

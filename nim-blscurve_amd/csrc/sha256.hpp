@@ -58,7 +58,7 @@ BLS_HD void sha256_begin(sha256_ctx& c) {
     c.total = 0;
 }
 
-BLS_HDN void sha256_put(sha256_ctx& c, uint8_t byte) {
+BLS_MID void sha256_put(sha256_ctx& c, uint8_t byte) {
     uint32_t idx = c.fill >> 2, sh = 24 - 8 * (c.fill & 3);
     // static-index update keeps w[] in registers
 #pragma unroll
