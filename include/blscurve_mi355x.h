@@ -106,6 +106,27 @@ int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const 
 int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_points, size_t npoints,
                                         const void* d_scalars, size_t nbits, void* stream);
 
+/* Batched PublicKey.fromBytes / Signature.fromBytes (blscurve/blst/bls_sig_io.nim:42-58, 81-99) on the device:
+ * n compressed public keys (48 B each), 32-byte messages and compressed signatures (96 B each), ZCash format.
+ * Per tuple: blst_p1_uncompress, "public key is not infinity", blst_p1_affine_in_g1, blst_p2_uncompress,
+ * blst_p2_affine_in_g2 (an infinity signature is allowed).  status[i] (optional, n bytes): 0 ok, 1 bad pk
+ * encoding / x >= p / not on the curve, 2 pk not in G1, 3 pk infinity, 4 bad sig encoding, 5 sig not in G2.
+ * out_sets (optional): n x 320-byte SignatureSet records (failed tuples are zeroed).
+ * Returns 1 when every tuple deserialised, 0 when some did not, negative on runtime failure. */
+int mi355_bls_deserialize_sets(mi355_bls_ctx* ctx, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n,
+                               void* out_sets, uint8_t* status);
+int mi355_bls_deserialize_sets_device(mi355_bls_ctx* ctx, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
+                                      void* stream, void* out_sets, uint8_t* status);
+
+/* fromBytes for every tuple followed by batchVerify (bls_batch_verifier.nim:420-495), all on the device:
+ * the wire format (176 B per tuple) is the only thing that crosses PCIe.  Returns 0 if any tuple fails to
+ * deserialise (the caller would not have obtained a SignatureSet) or the batch does not verify. */
+int mi355_bls_batch_verify_compressed(mi355_bls_ctx* ctx, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n,
+                                      const uint8_t rnd[32], uint8_t* status);
+int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* ctx, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
+                                             const uint8_t rnd[32], void* stream, uint8_t* status);
+float mi355_bls_last_deser_ms(mi355_bls_ctx* ctx);   /* duration of the deserialisation kernel of the last compressed call */
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

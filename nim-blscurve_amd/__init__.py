@@ -63,6 +63,13 @@ def lib():
         L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.restype = sz
         L.mi355_bls_p1s_mult_pippenger.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
         L.mi355_bls_p1s_mult_pippenger_device.argtypes = [vp, ctypes.c_char_p, vp, sz, vp, sz, vp]
+        cp = ctypes.c_char_p
+        L.mi355_bls_deserialize_sets.argtypes = [vp, cp, cp, cp, sz, vp, vp]
+        L.mi355_bls_deserialize_sets_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+        L.mi355_bls_batch_verify_compressed.argtypes = [vp, cp, cp, cp, sz, cp, vp]
+        L.mi355_bls_batch_verify_compressed_device.argtypes = [vp, vp, vp, vp, sz, cp, vp, vp]
+        L.mi355_bls_last_deser_ms.argtypes = [vp]
+        L.mi355_bls_last_deser_ms.restype = ctypes.c_float
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
@@ -225,3 +232,34 @@ def p1s_mult_pippenger_device(cache, d_points, n, d_scalars, nbits=255, stream=0
     out = ctypes.create_string_buffer(144)
     _check(lib().mi355_bls_p1s_mult_pippenger_device(cache._h, out, d_points, n, d_scalars, nbits, stream))
     return out.raw
+
+
+def _split_compressed(pubkeys, messages, signatures):
+    pk = bytes(pubkeys) if isinstance(pubkeys, (bytes, bytearray, memoryview)) else b"".join(pubkeys)
+    ms = bytes(messages) if isinstance(messages, (bytes, bytearray, memoryview)) else b"".join(messages)
+    sg = bytes(signatures) if isinstance(signatures, (bytes, bytearray, memoryview)) else b"".join(signatures)
+    if len(pk) % 48 or len(ms) % 32 or len(sg) % 96 or not (len(pk) // 48 == len(ms) // 32 == len(sg) // 96):
+        raise ValueError("n x 48-byte compressed keys, n x 32-byte messages, n x 96-byte compressed signatures")
+    return pk, ms, sg, len(pk) // 48
+
+
+def deserializeSets(cache, pubkeys, messages, signatures):
+    """Batched PublicKey.fromBytes / Signature.fromBytes (bls_sig_io.nim:42-58,81-99).
+    -> (all_ok, n x 320-byte SignatureSet records, per-tuple status bytes)."""
+    pk, ms, sg, n = _split_compressed(pubkeys, messages, signatures)
+    if n == 0:
+        return True, b"", b""
+    out = ctypes.create_string_buffer(320 * n)
+    st = ctypes.create_string_buffer(n)
+    ok = _check(lib().mi355_bls_deserialize_sets(cache._h, pk, ms, sg, n, out, st))
+    return bool(ok), out.raw, st.raw
+
+
+def batchVerifyCompressed(cache, pubkeys, messages, signatures, secureRandomBytes):
+    """fromBytes for every tuple, then batchVerify, on the device.  -> (verdict, per-tuple status bytes)."""
+    pk, ms, sg, n = _split_compressed(pubkeys, messages, signatures)
+    if n == 0:
+        return False, b""
+    st = ctypes.create_string_buffer(n)
+    ok = _check(lib().mi355_bls_batch_verify_compressed(cache._h, pk, ms, sg, n, bytes(secureRandomBytes), st))
+    return bool(ok), st.raw

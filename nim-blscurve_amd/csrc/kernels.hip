@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/blscurve_mi355x.h"
+#include "deser.hpp"
 #include "h2c.hpp"
 #include "pairing.hpp"
 
@@ -837,6 +838,30 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_deser: one lane per tuple: compressed public key (48 B) + signature (96 B) -> validated
+// SignatureSet record (320 B, BLST images) + status byte.  Replaces PublicKey.fromBytes /
+// Signature.fromBytes per tuple (bls_sig_io.nim:42-58,81-99).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_deser(const uint8_t* __restrict__ pks, const uint8_t* __restrict__ msgs, const uint8_t* __restrict__ sigs,
+                                                uint32_t n, uint8_t* __restrict__ sets, uint8_t* __restrict__ status, uint32_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    g1_aff pk;
+    g2_aff sg;
+    uint8_t st = deserialize_tuple(pk, sg, pks + (size_t)i * 48, sigs + (size_t)i * 96);
+    status[i] = st;
+    if (st != DESER_OK) atomicOr(flags + 2, 1u);
+    uint32_t* o = reinterpret_cast<uint32_t*>(sets + (size_t)i * 320);
+    bool ok = st == DESER_OK;
+    pk = g1_aff{fp_select(ok, pk.x, fp_zero()), fp_select(ok, pk.y, fp_zero())};
+    sg = g2_aff{fp2_select(ok, sg.x, fp2_zero()), fp2_select(ok, sg.y, fp2_zero())};
+    st_fp_blst(o, pk.x); st_fp_blst(o + 12, pk.y);
+    const uint8_t* m = msgs + (size_t)i * 32;
+    for (int j = 0; j < 8; j++) o[24 + j] = (uint32_t)m[4 * j] | ((uint32_t)m[4 * j + 1] << 8) | ((uint32_t)m[4 * j + 2] << 16) | ((uint32_t)m[4 * j + 3] << 24);
+    st_fp_blst(o + 32, sg.x.c0); st_fp_blst(o + 44, sg.x.c1); st_fp_blst(o + 56, sg.y.c0); st_fp_blst(o + 68, sg.y.c1);
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -889,6 +914,10 @@ struct mi355_bls_ctx {
     uint32_t* d_agg = nullptr;
     uint32_t* d_agg1 = nullptr;      // G1 aggregate (blst_p1 image)
     uint8_t* d_msg = nullptr;        // message (<= 4096 B) + signature staging
+    uint8_t* d_comp = nullptr;       // compressed wire-format staging: cap x (48 + 32 + 96) bytes
+    uint8_t* d_status = nullptr;     // per-tuple deserialisation status
+    hipEvent_t ev_deser0 = nullptr, ev_deser1 = nullptr;
+    float deser_ms = 0.f;
     uint32_t* d_lpart = nullptr;
     uint32_t* d_L = nullptr;
     uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
@@ -913,12 +942,14 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_agg1, c->d_msg, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->ev_deser0) (void)hipEventDestroy(c->ev_deser0);
+    if (c->ev_deser1) (void)hipEventDestroy(c->ev_deser1);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->msm) {
         msm_free(c->msm);
@@ -965,6 +996,8 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
     ALLOC(c->d_msg, 4096 + 192);
+    ALLOC(c->d_comp, max_sets * 176);
+    ALLOC(c->d_status, max_sets);
     ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * F12W * 4);
     ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
@@ -974,6 +1007,8 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_deser0));
+    HIPCHK(hipEventCreate(&c->ev_deser1));
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -1389,3 +1424,87 @@ extern "C" int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p1[144
     HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars[0], npoints * 32, hipMemcpyHostToDevice, nullptr));
     return mi355_bls_p1s_mult_pippenger_device(c, ret_p1, c->msm->d_pts, npoints, c->msm->d_sc, nbits, nullptr);
 }
+
+// ------------------------------------------------------------------------------------------
+// Wire-format entry points: batched fromBytes (+ batchVerify)
+// ------------------------------------------------------------------------------------------
+static int deser_enqueue(mi355_bls_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint8_t* d_sigs, size_t n, hipStream_t st) {
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    k_deser<<<((uint32_t)n + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_pks, d_msgs, d_sigs, (uint32_t)n, c->d_sets, c->d_status, c->d_flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi355_bls_deserialize_sets_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n, void* stream,
+                                                 void* out_sets, uint8_t* status) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 1;
+    if (!d_pks48 || !d_msgs32 || !d_sigs96) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    uint32_t fl[4];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+    if (out_sets) HIPCHK(hipMemcpyAsync(out_sets, c->d_sets, n * 320, hipMemcpyDeviceToHost, st));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    HIPCHK(hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]));
+    c->timings[7] = c->timings[0];
+    return fl[2] ? 0 : 1;
+}
+
+static int stage_compressed(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n) {
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_comp, pks, n * 48, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 48, msgs, n * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 80, sigs, n * 96, hipMemcpyHostToDevice, nullptr));
+    return 0;
+}
+
+extern "C" int mi355_bls_deserialize_sets(mi355_bls_ctx* c, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n, void* out_sets,
+                                          uint8_t* status) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 1;
+    if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
+    int rc = stage_compressed(c, pks48, msgs32, sigs96, n);
+    if (rc) return rc;
+    return mi355_bls_deserialize_sets_device(c, c->d_comp, c->d_comp + c->cap * 48, c->d_comp + c->cap * 80, n, nullptr, out_sets, status);
+}
+
+extern "C" int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
+                                                        const uint8_t rnd[32], void* stream, uint8_t* status) {
+    if (!c || !rnd) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!d_pks48 || !d_msgs32 || !d_sigs96) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev_deser0, st));
+    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_deser1, st));
+    uint32_t fl[4];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&c->deser_ms, c->ev_deser0, c->ev_deser1));
+    if (fl[2]) return 0;                                   // some fromBytes failed: the caller never gets to batchVerify
+    return verify_common(c, c->d_sets, n, rnd, 0, st);
+}
+
+extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n,
+                                                 const uint8_t rnd[32], uint8_t* status) {
+    if (!c || !rnd) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
+    int rc = stage_compressed(c, pks48, msgs32, sigs96, n);
+    if (rc) return rc;
+    return mi355_bls_batch_verify_compressed_device(c, c->d_comp, c->d_comp + c->cap * 48, c->d_comp + c->cap * 80, n, rnd, nullptr, status);
+}
+
+extern "C" float mi355_bls_last_deser_ms(mi355_bls_ctx* c) { return c ? c->deser_ms : 0.f; }

@@ -535,6 +535,89 @@ void oracle_make_pks(uint8_t* pks, size_t n, uint64_t seed) {
         oracle_sk_to_pk(sk, pks + 96 * (size_t)i);
     }
 }
+/* ------------------------------------------------------------------ deserialisation (bls_sig_io.nim:42-99), by the definitions:
+ * decompression through a square root, subgroup membership through [r]P == infinity */
+static int fp_from_be48(fp* out, const uint8_t* b, int clear_flags) {
+    fp v;
+    for (int i = 0; i < 6; i++) { uint64_t w = 0; for (int j = 0; j < 8; j++) w = (w << 8) | b[40 - 8 * i + j]; v.l[i] = w; }
+    if (clear_flags) v.l[5] &= 0x1fffffffffffffffull;
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) { u128 d = (u128)v.l[i] - K_P[i] - (uint64_t)br; br = (d >> 64) & 1; }
+    if (!br) return 0;                       /* >= p */
+    *out = fp_to_mont(&v); return 1;
+}
+static int fp_is_large(const fp* y_mont) {  /* canonical y > (p-1)/2 */
+    fp y = fp_from_mont(y_mont);
+    for (int i = 5; i >= 0; i--) { if (y.l[i] > K_PM1D2_INT[i]) return 1; if (y.l[i] < K_PM1D2_INT[i]) return 0; }
+    return 0;
+}
+/* returns 0 ok, 1 bad encoding; *inf for the infinity encoding */
+static int g1_uncompress(g1a* out, const uint8_t* b) {
+    memset(out, 0, sizeof *out);
+    if (!(b[0] & 0x80)) return 1;
+    if (b[0] & 0x40) { int any = b[0] & 0x3f; for (int i = 1; i < 48; i++) any |= b[i]; out->inf = 1; return any != 0; }
+    fp x; if (!fp_from_be48(&x, b, 1)) return 1;
+    fp x2 = fp_sqr(&x), x3 = fp_mul(&x2, &x), four = fp_small(4), rhs = fp_add(&x3, &four), y;
+    if (!fp_sqrt(&y, &rhs)) return 1;
+    if (fp_is_large(&y) != ((b[0] >> 5) & 1)) y = fp_neg(&y);
+    out->x = x; out->y = y; return 0;
+}
+static int g2_uncompress(g2a* out, const uint8_t* b) {
+    memset(out, 0, sizeof *out);
+    if (!(b[0] & 0x80)) return 1;
+    if (b[0] & 0x40) { int any = b[0] & 0x3f; for (int i = 1; i < 96; i++) any |= b[i]; out->inf = 1; return any != 0; }
+    fp2 x; if (!fp_from_be48(&x.c1, b, 1) || !fp_from_be48(&x.c0, b + 48, 0)) return 1;
+    fp2 x2 = f2_sqr(&x), x3 = f2_mul(&x2, &x), b2; b2.c0 = fp_small(4); b2.c1 = b2.c0;
+    fp2 rhs = f2_add(&x3, &b2), y;
+    if (!f2_sqrt(&y, &rhs)) return 1;
+    int large = fp_is_zero(&y.c1) ? fp_is_large(&y.c0) : fp_is_large(&y.c1);
+    if (large != ((b[0] >> 5) & 1)) y = f2_neg(&y);
+    out->x = x; out->y = y; return 0;
+}
+/* status bytes as in include/blscurve_mi355x.h; out320 may be NULL.  Returns 1 when every tuple deserialised. */
+int oracle_deserialize_sets(const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, uint8_t* out320, uint8_t* status) {
+    int all = 1;
+#pragma omp parallel for schedule(dynamic, 8) reduction(& : all)
+    for (long i = 0; i < (long)n; i++) {
+        g1a pk; g2a sg; uint8_t st = 0;
+        if (g1_uncompress(&pk, pks + 48 * i)) st = 1;
+        else if (pk.inf) st = 3;
+        else { g1j pj = g1_from_aff(&pk), t = g1_mul(&pj, K_R_LE, 255); if (!g1_is_inf(&t)) st = 2; }
+        if (!st) {
+            if (g2_uncompress(&sg, sigs + 96 * i)) st = 4;
+            else if (!sg.inf) { g2j sj = g2_from_aff(&sg), t = g2_mul(&sj, K_R_LE, 255); if (!g2_is_inf(&t)) st = 5; }
+        }
+        if (status) status[i] = st;
+        if (st) all = 0;
+        if (out320) {
+            uint8_t* o = out320 + 320 * (size_t)i;
+            if (st) memset(o, 0, 320);
+            else { st_g1a(o, &pk); memcpy(o + 96, msgs + 32 * i, 32); st_g2a(o + 128, &sg); }
+            if (st) memcpy(o + 96, msgs + 32 * i, 32);
+        }
+    }
+    return all;
+}
+/* ZCash compression of the 320-byte records (for building wire-format test inputs) */
+void oracle_compress_sets(const uint8_t* sets, size_t n, uint8_t* pks48, uint8_t* msgs32, uint8_t* sigs96) {
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* r = sets + 320 * i;
+        g1a pk = ld_g1a(r); g2a sg = ld_g2a(r + 128);
+        uint8_t* o = pks48 + 48 * i; memset(o, 0, 48);
+        if (pk.inf) o[0] = 0xc0;
+        else { fp x = fp_from_mont(&pk.x); for (int k = 0; k < 6; k++) for (int j = 0; j < 8; j++) o[40 - 8 * k + j] = (uint8_t)(x.l[k] >> (56 - 8 * j)); o[0] |= 0x80 | (fp_is_large(&pk.y) ? 0x20 : 0); }
+        memcpy(msgs32 + 32 * i, r + 96, 32);
+        o = sigs96 + 96 * i; memset(o, 0, 96);
+        if (sg.inf) o[0] = 0xc0;
+        else {
+            fp x1 = fp_from_mont(&sg.x.c1), x0 = fp_from_mont(&sg.x.c0);
+            for (int k = 0; k < 6; k++) for (int j = 0; j < 8; j++) { o[40 - 8 * k + j] = (uint8_t)(x1.l[k] >> (56 - 8 * j)); o[48 + 40 - 8 * k + j] = (uint8_t)(x0.l[k] >> (56 - 8 * j)); }
+            int large = fp_is_zero(&sg.y.c1) ? fp_is_large(&sg.y.c0) : fp_is_large(&sg.y.c1);
+            o[0] |= 0x80 | (large ? 0x20 : 0);
+        }
+    }
+}
+
 /* sum of affine G1 points (aggregateAll, core :179-195) -> affine */
 void oracle_g1_sum(const uint8_t* pts, size_t n, uint8_t out96[96]) {
     g1j acc = g1_inf();

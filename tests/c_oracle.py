@@ -20,6 +20,8 @@ def lib():
         L.oracle_g2_mul.argtypes = [cp, cp, cp]
         L.oracle_make_batch.argtypes = [vp, sz, ctypes.c_uint64]
         L.oracle_make_pks.argtypes = [vp, sz, ctypes.c_uint64]
+        L.oracle_deserialize_sets.argtypes = [cp, cp, cp, sz, vp, vp]
+        L.oracle_compress_sets.argtypes = [cp, sz, vp, vp, vp]
         L.oracle_g1_sum.argtypes = [cp, sz, cp]
         L.oracle_fast_aggregate_verify.argtypes = [cp, sz, cp, sz, cp]
         L.oracle_msm_g1.argtypes = [cp, cp, sz, i32, cp]
@@ -100,3 +102,17 @@ def make_pks(n, seed=0):
         sk[0] |= 1
         tot += int.from_bytes(sk, "little")
     return b.raw, tot % R
+
+
+def compress_sets(sets):
+    n = len(sets) // 320
+    pk, ms, sg = ctypes.create_string_buffer(48 * n), ctypes.create_string_buffer(32 * n), ctypes.create_string_buffer(96 * n)
+    lib().oracle_compress_sets(sets, n, pk, ms, sg)
+    return pk.raw, ms.raw, sg.raw
+
+
+def deserialize_sets(pks, msgs, sigs):
+    n = len(pks) // 48
+    out, st = ctypes.create_string_buffer(320 * n), ctypes.create_string_buffer(n)
+    ok = lib().oracle_deserialize_sets(pks, msgs, sigs, n, out, st)
+    return bool(ok), out.raw, st.raw

@@ -5,6 +5,7 @@
 #include "curve.hpp"
 #include "h2c.hpp"
 #include "pairing.hpp"
+#include "deser.hpp"
 using namespace bls;
 extern "C" {
 void emu_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_mul(fp_load_le(a), fp_load_le(b))); }
@@ -39,6 +40,18 @@ void emu_pairing_product(const uint8_t* ps, const uint8_t* qs, uint32_t n, uint8
     if (do_final_exp) f = final_exp(f);
     fp12_store_le(out, f);
 }
+// compressed -> blst affine image; returns 1 ok / 0 bad encoding; *inf set for the infinity encoding
+int emu_g1_uncompress(const uint8_t* b48, uint8_t* out96, int* inf) {
+    g1_aff a; bool i; bool ok = g1_uncompress(a, i, b48); *inf = i;
+    fp_store_le(out96, a.x); fp_store_le(out96 + 48, a.y); return ok;
+}
+int emu_g2_uncompress(const uint8_t* b96, uint8_t* out192, int* inf) {
+    g2_aff a; bool i; bool ok = g2_uncompress(a, i, b96); *inf = i;
+    fp2_store_le(out192, a.x); fp2_store_le(out192 + 96, a.y); return ok;
+}
+int emu_g1_in_subgroup(const uint8_t* aff96) { return g1_in_subgroup(g1_aff_load(aff96)); }
+int emu_g2_in_subgroup(const uint8_t* aff192) { return g2_in_subgroup(g2_aff_load(aff192)); }
+int emu_deserialize_tuple(const uint8_t* pk48, const uint8_t* sig96) { g1_aff p; g2_aff s; return deserialize_tuple(p, s, pk48, sig96); }
 void emu_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp12_store_le(r, fp12_mul(fp12_load_le(a), fp12_load_le(b))); }
 void emu_final_exp(const uint8_t* a, uint8_t* r) { fp12_store_le(r, final_exp(fp12_load_le(a))); }
 }

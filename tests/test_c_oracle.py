@@ -67,3 +67,21 @@ def test_g1_sum_msm_fav():
         assert co.fast_aggregate_verify(pks, msg, bytes.fromhex(v["sig"])) is True
         assert co.fast_aggregate_verify(pks, msg, bytes.fromhex(v["bad_sig"])) is False
     assert co.fast_aggregate_verify(b"", b"x", bytes(192)) is False
+
+
+def test_compress_deserialize_roundtrip_and_python_parity():
+    rec = co.make_batch(6, seed=3)
+    pk, ms, sg = co.compress_sets(rec)
+    for i in range(6):
+        assert pk[48 * i:48 * i + 48] == o.g1_compress(o.g1_from_blst_affine(rec[320 * i:320 * i + 96]))
+        assert sg[96 * i:96 * i + 96] == o.g2_compress(o.g2_from_blst_affine(rec[320 * i + 128:320 * i + 320]))
+    ok, out, st = co.deserialize_sets(pk, ms, sg)
+    assert ok and out == rec and st == bytes(6)
+    # reference KAT: malformed signature must be rejected (tests/serialization.nim:39-45)
+    bad = bytes([217, 149, 255, 97, 73, 133, 236, 43, 248, 34, 30, 10, 15, 45, 82, 72, 243, 179, 53, 17, 27, 17, 248, 180, 7, 92, 200, 153, 11, 3, 111, 137, 124, 171, 29, 218, 191, 246, 148, 57, 160, 50, 232, 129, 81, 90, 72, 161, 110, 138, 243, 116, 0, 88, 125, 180, 67, 153, 194, 181, 117, 152, 166, 147, 13, 77, 15, 91, 33, 50, 140, 199, 150, 10, 15, 10, 209, 165, 38, 57, 56, 114, 175, 29, 49, 11, 11, 126, 55, 189, 170, 46, 218, 240, 189, 144])
+    ok, out, st = co.deserialize_sets(pk[:48], ms[:32], bad)
+    assert not ok and st == bytes([4])
+    ok, out, st = co.deserialize_sets(bytes([0xc0]) + bytes(47), ms[:32], sg[:96])
+    assert not ok and st == bytes([3])
+    ok, out, st = co.deserialize_sets(pk[:48], ms[:32], bytes([0xc0]) + bytes(95))
+    assert ok and st == bytes([0]) and out[128:] == bytes(192)

@@ -1,0 +1,130 @@
+"""GPU parity: batched deserialisation + validation (bls_sig_io.nim:42-99) and the wire-format batch verify."""
+import random
+
+import pytest
+
+import bls12381_py as o
+from util import golden
+
+pytestmark = pytest.mark.gpu
+
+BAD_SIG = bytes([217, 149, 255, 97, 73, 133, 236, 43, 248, 34, 30, 10, 15, 45, 82, 72, 243, 179, 53, 17, 27, 17, 248, 180, 7, 92, 200, 153, 11, 3, 111, 137, 124, 171, 29, 218, 191, 246, 148, 57, 160, 50, 232, 129, 81, 90, 72, 161, 110, 138, 243, 116, 0, 88, 125, 180, 67, 153, 194, 181, 117, 152, 166, 147, 13, 77, 15, 91, 33, 50, 140, 199, 150, 10, 15, 10, 209, 165, 38, 57, 56, 114, 175, 29, 49, 11, 11, 126, 55, 189, 170, 46, 218, 240, 189, 144])
+
+
+@pytest.fixture(scope="module")
+def m():
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def cache(m):
+    return m.BatchedBLSVerifierCache.init(max_sets=4096, numThreads=4)
+
+
+def _curve_point_g1(rng):
+    while True:
+        x = rng.randrange(o.P)
+        y = o.fp_sqrt((x ** 3 + 4) % o.P)
+        if y is not None:
+            return (x, y)
+
+
+def _curve_point_g2(rng):
+    while True:
+        x = (rng.randrange(o.P), rng.randrange(o.P))
+        y = o.f2sqrt(o.f2add(o.f2mul(o.f2sqr(x), x), o.B2))
+        if y is not None:
+            return (x, y)
+
+
+def test_golden_cases_through_wire_format(m, cache):
+    """every tests/t_batch_verifier.nim scenario, fed as compressed bytes"""
+    for c in golden("batch")["cases"]:
+        rec, rnd, n = bytes.fromhex(c["sets"]), bytes.fromhex(c["rnd"]), c["n"]
+        pts = [(o.g1_from_blst_affine(rec[320 * i:320 * i + 96]), rec[320 * i + 96:320 * i + 128],
+                o.g2_from_blst_affine(rec[320 * i + 128:320 * i + 320])) for i in range(n)]
+        pk = b"".join(o.g1_compress(p) for p, _, _ in pts)
+        ms = b"".join(mm for _, mm, _ in pts)
+        sg = b"".join(o.g2_compress(s) for _, _, s in pts)
+        ok, out, st = m.deserializeSets(cache, pk, ms, sg)
+        if c["name"] == "inf_pk":
+            assert not ok and st[1] == 3
+            v, st2 = m.batchVerifyCompressed(cache, pk, ms, sg, rnd)
+            assert v is False and st2 == st
+            continue
+        assert ok and st == bytes(n) and out == rec          # byte-exact SignatureSet records
+        v, st2 = m.batchVerifyCompressed(cache, pk, ms, sg, rnd)
+        assert v == c["expect"] and st2 == bytes(n)
+
+
+def test_invalid_encodings_and_subgroup(m, cache):
+    rng = random.Random(77)
+    good_pk = o.g1_compress(o.g1_mul(o.G1_GEN, 1234567))
+    good_sg = o.g2_compress(o.g2_mul(o.G2_GEN, 7654321))
+    msg = bytes(range(32))
+    x = 1
+    while o.fp_sqrt((x ** 3 + 4) % o.P) is not None:
+        x += 1
+    cases = [
+        (good_pk, good_sg, 0),
+        (bytes([good_pk[0] & 0x7f]) + good_pk[1:], good_sg, 1),                 # not flagged compressed
+        ((o.P | (1 << 383)).to_bytes(48, "big"), good_sg, 1),                   # x = p
+        ((x | (1 << 383)).to_bytes(48, "big"), good_sg, 1),                     # x not on the curve
+        (bytes([0xc0]) + bytes(46) + b"\x01", good_sg, 1),                      # infinity with payload
+        (bytes([0xc0]) + bytes(47), good_sg, 3),                                # infinity public key
+        (o.g1_compress(_curve_point_g1(rng)), good_sg, 2),                      # on the curve, outside G1
+        (good_pk, BAD_SIG, 4),                                                  # tests/serialization.nim:39-45
+        (good_pk, bytes([good_sg[0] & 0x7f]) + good_sg[1:], 4),
+        (good_pk, o.g2_compress(_curve_point_g2(rng)), 5),                      # on the curve, outside G2
+        (good_pk, bytes([0xc0]) + bytes(95), 0),                                # infinity signature is allowed
+        (o.g1_compress(o.g1_neg(o.g1_mul(o.G1_GEN, 99))), o.g2_compress(o.g2_neg(o.g2_mul(o.G2_GEN, 5))), 0),
+    ]
+    pk = b"".join(c[0] for c in cases)
+    sg = b"".join(c[1] for c in cases)
+    ok, out, st = m.deserializeSets(cache, pk, msg * len(cases), sg)
+    assert list(st) == [c[2] for c in cases] and not ok
+    for i, c in enumerate(cases):
+        r = out[320 * i:320 * i + 320]
+        if c[2] == 0:
+            assert r[:96] == o.g1_to_blst_affine(o.g1_decompress(c[0])) and r[128:] == o.g2_to_blst_affine(o.g2_decompress(c[1]))
+        else:
+            assert r[:96] == bytes(96) and r[128:] == bytes(192)
+    assert m.deserializeSets(cache, b"", b"", b"") == (True, b"", b"")
+    assert m.batchVerifyCompressed(cache, b"", b"", b"", bytes(32)) == (False, b"")
+
+
+def test_scale_vs_c_oracle(m, cache):
+    """4096 distinct valid tuples + sprinkled invalid ones: statuses and records equal the C restatement's
+    (decompression by square root, membership by [r]P)."""
+    import c_oracle as co
+    rng = random.Random(5)
+    n = 4096
+    rec = co.make_batch(n, seed=11)
+    pk, ms, sg = co.compress_sets(rec)
+    rnd = o.sha256(b"Mr F was here")
+    v, st = m.batchVerifyCompressed(cache, pk, ms, sg, rnd)
+    assert v is True and st == bytes(n)
+    print("deser ms:", m.lib().mi355_bls_last_deser_ms(cache._h), cache.timings())
+    pkb, sgb = bytearray(pk), bytearray(sg)
+    bad_pk = o.g1_compress(_curve_point_g1(rng))
+    bad_sg = o.g2_compress(_curve_point_g2(rng))
+    for i in (3, 1000, 4095):
+        pkb[48 * i:48 * i + 48] = bad_pk
+    for i in (7, 2048):
+        sgb[96 * i:96 * i + 96] = bad_sg
+    sgb[96 * 100:96 * 100 + 96] = BAD_SIG
+    okc, outc, stc = co.deserialize_sets(bytes(pkb), ms, bytes(sgb))
+    ok, out, st = m.deserializeSets(cache, bytes(pkb), ms, bytes(sgb))
+    assert (ok, st) == (okc, stc) and not ok
+    for i in range(n):
+        if st[i] == 0:
+            assert out[320 * i:320 * i + 320] == outc[320 * i:320 * i + 320]
+    v, st2 = m.batchVerifyCompressed(cache, bytes(pkb), ms, bytes(sgb), rnd)
+    assert v is False and st2 == st
+    # a valid encoding of a different (valid) signature: deserialises, batch must not verify
+    sgc = bytearray(sg)
+    sgc[0:96], sgc[96:192] = sg[96:192], sg[0:96]
+    v, st3 = m.batchVerifyCompressed(cache, pk, ms, bytes(sgc), rnd)
+    assert v is False and st3 == bytes(n)

@@ -109,3 +109,84 @@ def test_pairing_projective_inputs_and_product(emu):
     qs3 = qs + g2_aff_to_jac_bytes(q)
     emu.emu_pairing_product(ps3, qs3, 3, out, 1)
     assert fp12_from_bytes(out.raw) == o.F12_ONE
+
+
+def _random_curve_point_g1(rng):
+    """A random point of E1(Fp) (almost surely NOT in G1: cofactor 0x396c8c005555e1568c00aaab0000aaab)."""
+    while True:
+        x = rng.randrange(o.P)
+        y = o.fp_sqrt((x ** 3 + 4) % o.P)
+        if y is not None:
+            return (x, y)
+
+
+def _random_curve_point_g2(rng):
+    while True:
+        x = (rng.randrange(o.P), rng.randrange(o.P))
+        y = o.f2sqrt(o.f2add(o.f2mul(o.f2sqr(x), x), o.B2))
+        if y is not None:
+            return (x, y)
+
+
+def test_deserialisation(emu):
+    """bls_sig_io.nim:42-99 semantics: uncompress + subgroup checks, against the oracle's definitions
+    (decompression by sqrt, membership by [r]P == infinity)."""
+    rng = random.Random(2024)
+    inf = ctypes.c_int()
+    for _ in range(4):
+        sk = rng.randrange(1, o.R)
+        p = o.g1_mul(o.G1_GEN, sk)
+        for pt in (p, o.g1_neg(p)):
+            out = buf(96)
+            assert emu.emu_g1_uncompress(o.g1_compress(pt), out, ctypes.byref(inf)) == 1 and inf.value == 0
+            assert out.raw == o.g1_to_blst_affine(pt)
+            assert emu.emu_g1_in_subgroup(out.raw) == 1
+        q = o.g2_mul(o.G2_GEN, sk)
+        for pt in (q, o.g2_neg(q)):
+            out = buf(192)
+            assert emu.emu_g2_uncompress(o.g2_compress(pt), out, ctypes.byref(inf)) == 1 and inf.value == 0
+            assert out.raw == o.g2_to_blst_affine(pt)
+            assert emu.emu_g2_in_subgroup(out.raw) == 1
+    # points on the curve but outside the subgroup: decompress fine, membership false (oracle: [r]P != inf)
+    for _ in range(4):
+        p = _random_curve_point_g1(rng)
+        assert not o.g1_in_subgroup(p)
+        out = buf(96)
+        assert emu.emu_g1_uncompress(o.g1_compress(p), out, ctypes.byref(inf)) == 1
+        assert out.raw == o.g1_to_blst_affine(p)
+        assert emu.emu_g1_in_subgroup(out.raw) == 0
+        q = _random_curve_point_g2(rng)
+        assert not o.g2_in_subgroup(q)
+        out = buf(192)
+        assert emu.emu_g2_uncompress(o.g2_compress(q), out, ctypes.byref(inf)) == 1
+        assert out.raw == o.g2_to_blst_affine(q)
+        assert emu.emu_g2_in_subgroup(out.raw) == 0
+    # clearing the cofactor of a random curve point lands in the subgroup
+    hp = o.g1_mul(_random_curve_point_g1(rng), o.H1)
+    assert emu.emu_g1_in_subgroup(o.g1_to_blst_affine(hp)) == 1
+    # encodings
+    out = buf(192)
+    assert emu.emu_g2_uncompress(bytes([0xc0]) + bytes(95), out, ctypes.byref(inf)) == 1 and inf.value == 1   # serialization.nim:19-29
+    bad = bytes([217, 149, 255, 97, 73, 133, 236, 43, 248, 34, 30, 10, 15, 45, 82, 72, 243, 179, 53, 17, 27, 17, 248, 180, 7, 92, 200, 153, 11, 3, 111, 137, 124, 171, 29, 218, 191, 246, 148, 57, 160, 50, 232, 129, 81, 90, 72, 161, 110, 138, 243, 116, 0, 88, 125, 180, 67, 153, 194, 181, 117, 152, 166, 147, 13, 77, 15, 91, 33, 50, 140, 199, 150, 10, 15, 10, 209, 165, 38, 57, 56, 114, 175, 29, 49, 11, 11, 126, 55, 189, 170, 46, 218, 240, 189, 144])
+    assert emu.emu_g2_uncompress(bad, out, ctypes.byref(inf)) == 0                                            # serialization.nim:39-45
+    good = o.g1_compress(o.g1_mul(o.G1_GEN, 5))
+    out = buf(96)
+    assert emu.emu_g1_uncompress(bytes([good[0] & 0x7f]) + good[1:], out, ctypes.byref(inf)) == 0           # compression flag missing
+    assert emu.emu_g1_uncompress(bytes([0xc0]) + bytes(46) + b"\x01", out, ctypes.byref(inf)) == 0           # infinity with payload
+    assert emu.emu_g1_uncompress(bytes([0xe0]) + bytes(47), out, ctypes.byref(inf)) == 0                     # infinity with sign bit
+    xp = (o.P | (1 << 383)).to_bytes(48, "big")
+    assert emu.emu_g1_uncompress(xp, out, ctypes.byref(inf)) == 0                                             # x = p
+    # an x with no point on the curve
+    x = 1
+    while o.fp_sqrt((x ** 3 + 4) % o.P) is not None:
+        x += 1
+    assert emu.emu_g1_uncompress((x | (1 << 383)).to_bytes(48, "big"), out, ctypes.byref(inf)) == 0
+    # tuple statuses
+    pk = o.g1_compress(o.g1_mul(o.G1_GEN, 7))
+    sg = o.g2_compress(o.g2_mul(o.G2_GEN, 9))
+    assert emu.emu_deserialize_tuple(pk, sg) == 0
+    assert emu.emu_deserialize_tuple(bytes([0xc0]) + bytes(47), sg) == 3
+    assert emu.emu_deserialize_tuple(o.g1_compress(_random_curve_point_g1(rng)), sg) == 2
+    assert emu.emu_deserialize_tuple(pk, o.g2_compress(_random_curve_point_g2(rng))) == 5
+    assert emu.emu_deserialize_tuple(pk, bad) == 4
+    assert emu.emu_deserialize_tuple(pk, bytes([0xc0]) + bytes(95)) == 0                                      # infinity signature allowed
