@@ -127,6 +127,15 @@ int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* ctx, const void* d_p
                                              const uint8_t rnd[32], void* stream, uint8_t* status);
 float mi355_bls_last_deser_ms(mi355_bls_ctx* ctx);   /* duration of the deserialisation kernel of the last compressed call */
 
+/* combine(secureRandomBytes, publicKeys, signatures) (blst_min_pubkey_sig_core.nim:570-647; called by
+ * MultiSignatureSet.combine, bls_batch_verifier.nim:100-106): linear combination of n signatures on ONE message.
+ * Scalars: chain seeded with rnd itself, taking the u64 words 3,2,1,0 of each SHA-256 output, zeros skipped
+ * (:588-606); out_pk = sum [s_i]PK_i and out_sig = sum [s_i]S_i as affine BLST images (the reference's two
+ * 64-bit Pippenger calls + finish).  n == 1: passthrough; n == 0: MI355_BLS_ERR_ARG (the reference asserts).
+ * pks: n x 96 B, sigs: n x 192 B, host memory.  Returns 0 on success. */
+int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks, const void* sigs, size_t n, uint8_t out_pk[96],
+                      uint8_t out_sig[192]);
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

@@ -70,6 +70,7 @@ def lib():
         L.mi355_bls_batch_verify_compressed_device.argtypes = [vp, vp, vp, vp, sz, cp, vp, vp]
         L.mi355_bls_last_deser_ms.argtypes = [vp]
         L.mi355_bls_last_deser_ms.restype = ctypes.c_float
+        L.mi355_bls_combine.argtypes = [vp, cp, cp, cp, sz, cp, cp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
@@ -263,3 +264,32 @@ def batchVerifyCompressed(cache, pubkeys, messages, signatures, secureRandomByte
     st = ctypes.create_string_buffer(n)
     ok = _check(lib().mi355_bls_batch_verify_compressed(cache._h, pk, ms, sg, n, bytes(secureRandomBytes), st))
     return bool(ok), st.raw
+
+
+class MultiSignatureSet:
+    """bls_batch_verifier.nim:47-106: signatures that all pertain to the same 32-byte message."""
+
+    def __init__(self, pubkeys, message, signatures):
+        pubkeys, signatures = list(pubkeys), list(signatures)
+        assert len(pubkeys) == len(signatures) and len(pubkeys) > 0          # doAssert :80-81
+        self.pubkeys, self.message, self.signatures = pubkeys, bytes(message), signatures
+
+    @classmethod
+    def init(cls, pubkeys, message=None, signatures=None):
+        if message is None:                       # init(sigset: SignatureSet)  (:89-94)
+            pk, msg, sig = pubkeys
+            return cls([pk], msg, [sig])
+        return cls(pubkeys, message, signatures)
+
+    def add(self, sigset):
+        pk, msg, sig = sigset
+        assert bytes(msg) == self.message                                     # doAssert :97
+        self.pubkeys.append(pk)
+        self.signatures.append(sig)
+
+    def combine(self, cache, secureRandomBytes):
+        """-> SignatureSet (pubkey96, message32, signature192)."""
+        n = len(self.pubkeys)
+        out_pk, out_sig = ctypes.create_string_buffer(96), ctypes.create_string_buffer(192)
+        _check(lib().mi355_bls_combine(cache._h, bytes(secureRandomBytes), b"".join(self.pubkeys), b"".join(self.signatures), n, out_pk, out_sig))
+        return (out_pk.raw, self.message, out_sig.raw)

@@ -246,7 +246,7 @@ __device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
                        b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13]);
 }
 #else
-__host__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
+__host__ __device__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
 #if defined(BLS_TRACK_BOUNDS)
     BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(b) <= 2048, "fp_mul value bounds");
     const int64_t LIM = (1ll << 29) + (1ll << 20);     // limb-wise sum of two semi-normalised values, not three
@@ -257,7 +257,7 @@ __host__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
 #endif
     return fp_mul_core(a, b);
 }
-__host__ __noinline__ inline fp fp_sqr(const fp& a) {
+__host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
 #if defined(BLS_TRACK_BOUNDS)
     BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(a) <= 2048, "fp_sqr value bounds");
     for (int i = 0; i < FP_N; i++) {

@@ -258,11 +258,13 @@ __global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets
     soa_st_g1(P, stride, i, q);
 }
 
-__global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint32_t* __restrict__ part) {
+// points are blst_p2_affine images at base + i*stride + offset (SignatureSet records: stride 320, offset 128)
+__global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ sets, size_t stride_b, size_t offset_b, uint32_t n, const uint64_t* __restrict__ r,
+                                                 uint32_t* __restrict__ part) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     g2_jac acc = jac_inf<fp2>();
     if (i < n) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 128);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * stride_b + offset_b);
         g2_aff s = ld_g2a_blst(w);
         acc = jac_mul_u64(s, r[i]);                 // infinity signature -> infinity (contributes nothing)
     }
@@ -862,6 +864,65 @@ __global__ void __launch_bounds__(WAVE) k_deser(const uint8_t* __restrict__ pks,
     st_fp_blst(o + 32, sg.x.c0); st_fp_blst(o + 44, sg.x.c1); st_fp_blst(o + 56, sg.y.c0); st_fp_blst(o + 68, sg.y.c1);
 }
 
+// ------------------------------------------------------------------------------------------
+// MultiSignatureSet.combine (blst_min_pubkey_sig_core.nim:570-647): same-message pre-aggregation
+//   s_i: chain seeded with rnd ITSELF, u64 words 3,2,1,0 of every digest, zeros skipped (:588-606)
+//   pk' = sum [s_i]PK_i, sig' = sum [s_i]S_i  (the reference's two 64-bit Pippenger calls, :629-646)
+// ------------------------------------------------------------------------------------------
+__global__ void k_combine_scalars(const uint8_t* __restrict__ rnd, uint32_t n, uint64_t* __restrict__ s_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t seed[8];
+    for (int i = 0; i < 8; i++) seed[i] = ((uint32_t)rnd[4 * i] << 24) | ((uint32_t)rnd[4 * i + 1] << 16) | ((uint32_t)rnd[4 * i + 2] << 8) | rnd[4 * i + 3];
+    int avail = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        for (;;) {
+            if (avail == 0) {
+                uint32_t nx[8];
+                sha256_of_digest(seed, nx);
+                for (int j = 0; j < 8; j++) seed[j] = nx[j];
+                avail = 4;
+            }
+            avail--;
+            uint64_t w = (uint64_t)bswap32(seed[2 * avail]) | ((uint64_t)bswap32(seed[2 * avail + 1]) << 32);   // LE u64 word `avail`
+            if (w != 0) {
+                s_out[i] = w;
+                break;
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_g1mul_sum(const uint8_t* __restrict__ pts, size_t stride_b, size_t offset_b, uint32_t n, const uint64_t* __restrict__ r,
+                                                    uint32_t* __restrict__ part) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    g1_jac acc = jac_inf<fp>();
+    if (i < n) acc = jac_mul_u64(ld_g1a_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * stride_b + offset_b)), r[i]);
+    for (int d = 32; d >= 1; d >>= 1) {
+        g1_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) st_g1_int(part + (size_t)blockIdx.x * G1W, acc);
+}
+// `finish` (to affine, core :172-177 / blst_p{1,2}_to_affine): Jacobian blst images -> affine blst images
+__global__ void k_finish_affine(const uint32_t* __restrict__ p1, const uint32_t* __restrict__ p2, uint32_t* __restrict__ out_pk, uint32_t* __restrict__ out_sig) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1_jac a = ld_g1_blst(p1);
+    if (jac_is_inf(a)) {
+        for (int i = 0; i < 24; i++) out_pk[i] = 0;
+    } else {
+        fp zi = fp_inv(a.z), zi2 = fp_sqr(zi);
+        st_fp_blst(out_pk, fp_mul(a.x, zi2));
+        st_fp_blst(out_pk + 12, fp_mul(a.y, fp_mul(zi2, zi)));
+    }
+    g2_jac b{fp2{ld_fp_blst(p2), ld_fp_blst(p2 + 12)}, fp2{ld_fp_blst(p2 + 24), ld_fp_blst(p2 + 36)}, fp2{ld_fp_blst(p2 + 48), ld_fp_blst(p2 + 60)}};
+    if (jac_is_inf(b)) {
+        for (int i = 0; i < 48; i++) out_sig[i] = 0;
+    } else {
+        fp2 zi = fp2_inv(b.z), zi2 = fp2_sqr(zi);
+        fp2 x = fp2_mul(b.x, zi2), y = fp2_mul(b.y, fp2_mul(zi2, zi));
+        st_fp_blst(out_sig, x.c0); st_fp_blst(out_sig + 12, x.c1); st_fp_blst(out_sig + 24, y.c0); st_fp_blst(out_sig + 36, y.c1);
+    }
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1053,7 +1114,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[3], st));
-    k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_spart);
+    k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, 320, 128, n32, c->d_r, c->d_spart);
     if (nb > 64) {          // two-level fold: 16 waves, then one
         uint32_t* part2 = c->d_spart + (size_t)nb * G2W;
         k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
@@ -1508,3 +1569,42 @@ extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t
 }
 
 extern "C" float mi355_bls_last_deser_ms(mi355_bls_ctx* c) { return c ? c->deser_ms : 0.f; }
+
+// ------------------------------------------------------------------------------------------
+// combine
+// ------------------------------------------------------------------------------------------
+extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const void* pks, const void* sigs, size_t n, uint8_t out_pk[96], uint8_t out_sig[192]) {
+    if (!c || !rnd || !pks || !sigs || !out_pk || !out_sig || n == 0) return MI355_BLS_ERR_ARG;     // n == 0: the reference raises (core :584)
+    if (n == 1) {                                                                                      // passthrough, no scalars (core :585-586)
+        memcpy(out_pk, pks, 96);
+        memcpy(out_sig, sigs, 192);
+        return 0;
+    }
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = nullptr;
+    uint8_t* d_pk = c->d_sets;                    // staging: n x 96 then n x 192 (<= n x 320)
+    uint8_t* d_sg = c->d_sets + n * 96;
+    HIPCHK(hipMemcpyAsync(d_pk, pks, n * 96, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sg, sigs, n * 192, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_rnd, rnd, 32, hipMemcpyHostToDevice, st));
+    uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    k_combine_scalars<<<1, 1, 0, st>>>(c->d_rnd, n32, c->d_r);
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    k_g1mul_sum<<<nb, WAVE, 0, st>>>(d_pk, 96, 0, n32, c->d_r, c->d_export);
+    k_g1_sum2<<<1, WAVE, 0, st>>>(c->d_export, nb, c->d_agg1);
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    k_sigmul<<<nb, WAVE, 0, st>>>(d_sg, 192, 0, n32, c->d_r, c->d_spart);
+    k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(c->d_msg);
+    k_finish_affine<<<1, 1, 0, st>>>(c->d_agg1, c->d_agg, d_out, d_out + 24);
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_pk, d_out, 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_sig, d_out + 24, 192, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->last_n = n;                  // fetch_stage(0) returns the combine scalars
+    return collect_timings(c, 4);
+}
