@@ -136,6 +136,14 @@ float mi355_bls_last_deser_ms(mi355_bls_ctx* ctx);   /* duration of the deserial
 int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks, const void* sigs, size_t n, uint8_t out_pk[96],
                       uint8_t out_sig[192]);
 
+/* aggregateVerify(publicKeys, messages, signature) (bls_sig_min_pubkey.nim:153-199; ContextCoreAggregateVerify,
+ * blst_min_pubkey_sig_core.nim:305-414): e(G1, sig) == prod_i e(pk_i, H(m_i)) for n (public key, message) pairs
+ * with messages of arbitrary length: message i = msgs[msg_offsets[i] .. msg_offsets[i+1]) (n + 1 offsets).
+ * pks: n x 96 B, sig: 192 B, host memory.  n == 0 -> 0; infinity public key -> 0.  The proofs of possession
+ * must have been checked by the caller, as for the reference's two-argument overloads. */
+int mi355_bls_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n,
+                               const void* sig);
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

@@ -71,6 +71,7 @@ def lib():
         L.mi355_bls_last_deser_ms.argtypes = [vp]
         L.mi355_bls_last_deser_ms.restype = ctypes.c_float
         L.mi355_bls_combine.argtypes = [vp, cp, cp, cp, sz, cp, cp]
+        L.mi355_bls_aggregate_verify.argtypes = [vp, cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
@@ -293,3 +294,18 @@ class MultiSignatureSet:
         out_pk, out_sig = ctypes.create_string_buffer(96), ctypes.create_string_buffer(192)
         _check(lib().mi355_bls_combine(cache._h, bytes(secureRandomBytes), b"".join(self.pubkeys), b"".join(self.signatures), n, out_pk, out_sig))
         return (out_pk.raw, self.message, out_sig.raw)
+
+
+def aggregateVerify(cache, publicKeys, messages, signature):
+    """bls_sig_min_pubkey.nim:153-174: one aggregate signature over distinct (public key, message) pairs.
+    Length mismatch or an empty list -> False."""
+    pks, msgs = list(publicKeys), [bytes(x) for x in messages]
+    if len(pks) != len(msgs) or len(pks) == 0:
+        return False
+    if any(len(p) != 96 for p in pks) or len(signature) != 192:
+        raise ValueError("public keys are 96-byte, the signature a 192-byte BLST affine image")
+    offs = [0]
+    for x in msgs:
+        offs.append(offs[-1] + len(x))
+    arr = (ctypes.c_uint32 * len(offs))(*offs)
+    return bool(_check(lib().mi355_bls_aggregate_verify(cache._h, b"".join(pks), b"".join(msgs) or b"\0", arr, len(pks), bytes(signature))))

@@ -923,6 +923,31 @@ __global__ void k_finish_affine(const uint32_t* __restrict__ p1, const uint32_t*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// aggregateVerify (bls_sig_min_pubkey.nim:153-199 -> ContextCoreAggregateVerify, core :305-414):
+// e(G1, sig) == prod e(pk_i, H(m_i)), distinct messages of any length, no blinding.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_hash_var(const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ offs, uint32_t n, dst_t dst,
+                                                   uint4* __restrict__ H, size_t stride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g2_jac h = hash_to_g2(msgs + offs[i], offs[i + 1] - offs[i], dst.b, dst.len);
+    soa_st_g2(H, stride, i, h);
+}
+// pairs 0..n-1: P = pk_i (affine, Z = 1); pair n: (P, Q) = (-G1, sig)
+__global__ void __launch_bounds__(WAVE) k_aggv_setup(const uint8_t* __restrict__ pks, uint32_t n, const uint32_t* __restrict__ sig, uint4* __restrict__ H,
+                                                     uint4* __restrict__ P, size_t stride, uint32_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        g1_aff pk = ld_g1a_blst(reinterpret_cast<const uint32_t*>(pks + (size_t)i * 96));
+        if (aff_is_inf(pk)) atomicOr(flags, 1u);                // BLST_PK_IS_INFINITY -> update() false
+        soa_st_g1(P, stride, i, jac_from_aff(pk));
+    } else if (i == n) {
+        soa_st_g1(P, stride, n, g1_jac{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()});
+        soa_st_g2(H, stride, n, jac_from_aff(ld_g2a_blst(sig)));
+    }
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1607,4 +1632,54 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
     HIPCHK(hipStreamSynchronize(st));
     c->last_n = n;                  // fetch_stage(0) returns the combine scalars
     return collect_timings(c, 4);
+}
+
+// ------------------------------------------------------------------------------------------
+// aggregateVerify
+// ------------------------------------------------------------------------------------------
+extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig) {
+    if (!c || !sig) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                                   // "Spec precondition" (bls_sig_min_pubkey.nim:165-167)
+    if (!pks || !msgs || !msg_offsets) return MI355_BLS_ERR_ARG;
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    size_t total = msg_offsets[n];
+    if (total + (n + 1) * 4 > c->cap * 320 - n * 96) return MI355_BLS_ERR_CAPACITY;     // staged in d_sets behind the keys
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = nullptr;
+    uint8_t* d_pk = c->d_sets;
+    uint32_t* d_off = reinterpret_cast<uint32_t*>(c->d_sets + n * 96);
+    uint8_t* d_msgs = c->d_sets + n * 96 + (n + 1) * 4;
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipMemcpyAsync(d_pk, pks, n * 96, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, msg_offsets, (n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_msgs, msgs, total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
+    uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE, nb1 = (n32 + 1 + WAVE - 1) / WAVE;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    k_hash_var<<<nb, WAVE, 0, st>>>(d_msgs, d_off, n32, c->dst, c->d_H, c->stride);
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    k_aggv_setup<<<nb1, WAVE, 0, st>>>(d_pk, n32, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    k_lines<<<nb1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    uint32_t np = n32 + 1, nblk = c->slots / N_LINES;
+    if (nblk < 1) nblk = 1;
+    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
+    uint32_t mm = (np + WAVE * nblk - 1) / (WAVE * nblk);
+    if (mm < 1) mm = 1;
+    nblk = (np + WAVE * mm - 1) / (WAVE * mm);
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, np, c->stride, mm, c->d_lpart, nblk);
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, 0xffffffffu, c->d_L);
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1);
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    HIPCHK(hipGetLastError());
+    uint32_t fl[2];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->have_gt = true;
+    c->last_n = 0;
+    int rc = collect_timings(c, 5);
+    if (rc) return rc;
+    return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
 }

@@ -145,3 +145,21 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
     bad[128:320], bad[320 + 128:640] = rec[320 + 128:640], rec[128:320]
     assert m.batchVerifyParallel(cache, bytes(bad), rnd) is False
     assert co.batch_verify(bytes(bad), rnd, nt) is False
+
+
+@pytest.mark.parametrize("n", [65537, 100003, 131072])
+def test_sizes_beyond_one_wave_per_simd(m, n):
+    """More than 64 x 1024 tuples (several rounds of waves, side-stream path on/off): all-valid -> true,
+    one swapped signature anywhere -> false.  Tuples are distinct for the first 8192, then tiled."""
+    import c_oracle as co
+    base = co.make_batch(8192, seed=123)
+    rec = (base * (n // 8192 + 1))[:320 * n]
+    rnd = o.sha256(b"Mr F was here")
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n)
+    assert m.batchVerify(cache, rec, rnd) is True
+    bad = bytearray(rec)
+    i, j = n - 1, n - 2
+    bad[320 * i + 128:320 * i + 320], bad[320 * j + 128:320 * j + 320] = rec[320 * j + 128:320 * j + 320], rec[320 * i + 128:320 * i + 320]
+    if rec[320 * i + 128:320 * i + 320] != rec[320 * j + 128:320 * j + 320]:
+        assert m.batchVerify(cache, bytes(bad), rnd) is False
+    cache.close()
