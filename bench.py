@@ -46,9 +46,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_DIST_BACKEND=gloo + BENCH_ALL_ON_DEVICE0=1 is a TEST HOOK: it lets the N > 1 code path (sharding, exchange,
+    # merge) run end to end on a box with a single GPU; real runs use RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_ALL_ON_DEVICE0") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -87,24 +92,34 @@ def main():
     assert count == n
 
     def all_gather(blob):
-        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        if backend == "nccl":
+            mine = mine.to(dev)
         allst = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allst, mine)               # RCCL; 584 B per rank
         return [bytes(t.cpu().numpy().tobytes()) for t in allst]
 
     stage_acc = {}
     acc_lock = __import__("threading").Lock()
+    free = __import__("queue").Queue()
+    for i in range(inflight):
+        free.put(i)
 
     def compute(it, record):
-        """The per-batch GPU work of one step on caller it % inflight; world > 1: this rank's shard state."""
-        c, st = caches[it % inflight], streams[it % inflight].cuda_stream
-        r = bytes(rnd)
-        out = c.verify_device(d_sets.data_ptr(), n, r, st) if world == 1 else c.shard_device(d_sets.data_ptr(), n_total, lo, hi, r, st)
-        if record:
-            with acc_lock:
-                for k, v in c.timings().items():
-                    stage_acc[k] = stage_acc.get(k, 0.0) + v
-        return out
+        """The per-batch GPU work of one step on a free caller context (a context is never shared by two
+        calls at a time); world > 1: this rank's shard state."""
+        slot = free.get()
+        try:
+            c, st = caches[slot], streams[slot].cuda_stream
+            r = bytes(rnd)
+            out = c.verify_device(d_sets.data_ptr(), n, r, st) if world == 1 else c.shard_device(d_sets.data_ptr(), n_total, lo, hi, r, st)
+            if record:
+                with acc_lock:
+                    for k, v in c.timings().items():
+                        stage_acc[k] = stage_acc.get(k, 0.0) + v
+            return out
+        finally:
+            free.put(slot)
 
     def run_steps(k, record):
         """k steps; the collective and the verdict of every step are issued in step order on this thread."""
@@ -134,7 +149,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     assert ok
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
