@@ -24,6 +24,16 @@ BLS_HD fp2 f_neg(const fp2& a) { return fp2_neg(a); }
 BLS_HD fp2 f_dbl(const fp2& a) { return fp2_dbl(a); }
 BLS_HD bool f_is_zero(const fp2& a) { return fp2_is_zero(a); }
 BLS_HD fp2 f_select(bool c, const fp2& a, const fp2& b) { return fp2_select(c, a, b); }
+// limb-wise (carry-less) variants: the caller carries (f_carry) or reduces (f_red) the end of the chain;
+// at most 7 limb units may pile up, and anything fed to a multiplication must be carried (see fp.hpp)
+BLS_HD fp f_add_nc(const fp& a, const fp& b) { return fp_add_nc(a, b); }
+BLS_HD fp f_sub_nc(const fp& a, const fp& b) { return fp_sub_nc(a, b); }
+BLS_HD fp f_dbl_nc(const fp& a) { return fp_dbl_nc(a); }
+BLS_HD fp f_carry(const fp& a) { return fp_carry(a); }
+BLS_HD fp2 f_add_nc(const fp2& a, const fp2& b) { return fp2_add_nc(a, b); }
+BLS_HD fp2 f_sub_nc(const fp2& a, const fp2& b) { return fp2_sub_nc(a, b); }
+BLS_HD fp2 f_dbl_nc(const fp2& a) { return fp2_dbl_nc(a); }
+BLS_HD fp2 f_carry(const fp2& a) { return fp2_carry(a); }
 // partial reduction (|v| < 0.51p): applied to stored coordinates so value bounds never accumulate
 BLS_HD fp f_red(const fp& a) { return fp_reduce(a); }
 BLS_HD fp2 f_red(const fp2& a) { return fp2_reduce(a); }
@@ -77,15 +87,14 @@ BLS_MID jac<F> jac_dbl(const jac<F>& p) {
     F A = f_sqr(p.x);
     F B = f_sqr(p.y);
     F C = f_sqr(B);
-    F D = f_sub(f_sub(f_sqr(f_add(p.x, B)), A), C);
-    D = f_dbl(D);
-    F E = f_add(f_dbl(A), A);
+    F D = f_carry(f_dbl_nc(f_sub_nc(f_sub_nc(f_sqr(f_add(p.x, B)), A), C)));     // 6 limb units, one carry
+    F E = f_carry(f_add_nc(f_dbl_nc(A), A));
     F Fq = f_sqr(E);
     jac<F> r;
-    r.x = f_red(f_sub(Fq, f_dbl(D)));
-    F C8 = f_dbl(f_dbl(f_dbl(C)));
-    r.y = f_red(f_sub(f_mul(E, f_sub(D, r.x)), C8));
-    r.z = f_red(f_dbl(f_mul(p.y, p.z)));
+    r.x = f_red(f_sub_nc(Fq, f_dbl_nc(D)));
+    F C8 = f_dbl_nc(f_carry(f_dbl_nc(f_dbl_nc(C))));
+    r.y = f_red(f_sub_nc(f_mul(E, f_sub(D, r.x)), C8));
+    r.z = f_red(f_dbl_nc(f_mul(p.y, p.z)));
     return r;
 }
 
@@ -105,8 +114,8 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     F HHH = f_mul(H, HH);
     F V = f_mul(p.x, HH);
     jac<F> r;
-    r.x = f_red(f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V)));
-    r.y = f_red(f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH)));
+    r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
+    r.y = f_red(f_sub_nc(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH)));
     r.z = f_red(f_mul(p.z, H));   // = 0 when P == -Q
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, jac_from_aff(q), r);
@@ -132,8 +141,8 @@ BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
     F HHH = f_mul(H, HH);
     F V = f_mul(U1, HH);
     jac<F> r;
-    r.x = f_red(f_sub(f_sub(f_sqr(rr), HHH), f_dbl(V)));
-    r.y = f_red(f_sub(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH)));
+    r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
+    r.y = f_red(f_sub_nc(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH)));
     r.z = f_red(f_mul(f_mul(p.z, q.z), H));
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, q, r);

@@ -44,9 +44,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <execinfo.h>
-#define BLS_VB_FIELD uint32_t vb;
+#define BLS_VB_FIELD uint32_t vb, lb;
 #define BLS_SET_VB(x, v) ((x).vb = (v))
 #define BLS_VB(x) ((x).vb)
+#define BLS_SET_LB(x, v) ((x).lb = (v))
+#define BLS_LB(x) ((x).lb)
 #define BLS_REQUIRE(cond, what)                                                         \
     do {                                                                                \
         if (!(cond)) {                                                                  \
@@ -60,6 +62,8 @@
 #define BLS_VB_FIELD
 #define BLS_SET_VB(x, v) ((void)0)
 #define BLS_VB(x) 0u
+#define BLS_SET_LB(x, v) ((void)0)
+#define BLS_LB(x) 0u
 #define BLS_REQUIRE(cond, what) ((void)0)
 #endif
 
@@ -78,6 +82,7 @@ BLS_HD fp fp_from_const(const uint32_t (&c)[FP_N]) {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = c[i];
     BLS_SET_VB(r, 1);
+    BLS_SET_LB(r, 1);
     return r;
 }
 
@@ -86,6 +91,7 @@ BLS_HD fp fp_zero() {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = 0;
     BLS_SET_VB(r, 1);
+    BLS_SET_LB(r, 1);
     return r;
 }
 
@@ -97,6 +103,7 @@ BLS_HD fp fp_select(bool c, const fp& a, const fp& b) {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = c ? a.l[i] : b.l[i];
     BLS_SET_VB(r, BLS_VB(a) > BLS_VB(b) ? BLS_VB(a) : BLS_VB(b));
+    BLS_SET_LB(r, BLS_LB(a) > BLS_LB(b) ? BLS_LB(a) : BLS_LB(b));
     return r;
 }
 
@@ -112,22 +119,16 @@ BLS_HD void fp_carry_step(uint32_t (&s)[FP_N]) {
     s[FP_N - 1] += c[FP_N - 2];
 }
 
-BLS_HD fp fp_add(const fp& a, const fp& b) {
-    fp r;
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] + b.l[i];
-    fp_carry_step(r.l);
-    BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
-    BLS_REQUIRE(BLS_VB(r) <= 1024, "fp_add value bound");
-    return r;
-}
-
-// limb-wise sum / difference with no carry step: |limbs| up to 2^29 + ..., only to be fed to fp_mul
+// Limb-magnitude bookkeeping (host tracker): lb = worst-case |limb| in units of 2^28.  Carried values have
+// lb 1; limb-wise ("_nc") operations add the operands' lb; int32 limbs hold at most 7 units; fp_mul / fp_sqr
+// accept lb <= 2.
 BLS_HD fp fp_add_nc(const fp& a, const fp& b) {
     fp r;
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] + b.l[i];
     BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    BLS_SET_LB(r, (BLS_LB(a) ? BLS_LB(a) : 1) + (BLS_LB(b) ? BLS_LB(b) : 1));
+    BLS_REQUIRE(BLS_LB(r) <= 7 && BLS_VB(r) <= 1024, "fp_add_nc bounds");
     return r;
 }
 BLS_HD fp fp_sub_nc(const fp& a, const fp& b) {
@@ -135,25 +136,40 @@ BLS_HD fp fp_sub_nc(const fp& a, const fp& b) {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] - b.l[i];
     BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
+    BLS_SET_LB(r, (BLS_LB(a) ? BLS_LB(a) : 1) + (BLS_LB(b) ? BLS_LB(b) : 1));
+    BLS_REQUIRE(BLS_LB(r) <= 7 && BLS_VB(r) <= 1024, "fp_sub_nc bounds");
     return r;
 }
-
-BLS_HD fp fp_sub(const fp& a, const fp& b) {
+// difference of two values whose limbs 0..12 are NON-NEGATIVE and below 2^28 (fresh multiplication results,
+// fp_reduce / fp_carry_full results): |limb| stays below 2^28, no carry needed
+BLS_HD fp fp_sub_pos(const fp& a, const fp& b) {
+    BLS_REQUIRE(BLS_LB(a) == 0 && BLS_LB(b) == 0, "fp_sub_pos needs canonical-limb operands");
     fp r;
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = a.l[i] - b.l[i];
-    fp_carry_step(r.l);
     BLS_SET_VB(r, BLS_VB(a) + BLS_VB(b));
-    BLS_REQUIRE(BLS_VB(r) <= 1024, "fp_sub value bound");
+    BLS_SET_LB(r, 1);
     return r;
 }
+// carry step on a limb-wise result: back to lb 1
+BLS_HD fp fp_carry(const fp& a) {
+    BLS_REQUIRE(BLS_LB(a) <= 7, "fp_carry limb bound");
+    fp r = a;
+    fp_carry_step(r.l);
+    BLS_SET_LB(r, 1);
+    return r;
+}
+BLS_HD fp fp_add(const fp& a, const fp& b) { return fp_carry(fp_add_nc(a, b)); }
+BLS_HD fp fp_sub(const fp& a, const fp& b) { return fp_carry(fp_sub_nc(a, b)); }
+BLS_HD fp fp_dbl_nc(const fp& a) { return fp_add_nc(a, a); }
 
+// limb-wise negation: magnitudes are unchanged, so no carry is needed
 BLS_HD fp fp_neg(const fp& a) {
     fp r;
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = 0u - a.l[i];
-    fp_carry_step(r.l);
     BLS_SET_VB(r, BLS_VB(a));
+    BLS_SET_LB(r, BLS_LB(a) ? BLS_LB(a) : 1);
     return r;
 }
 
@@ -188,6 +204,7 @@ BLS_HD fp fp_mul_core(const fp& a, const fp& b) {
     }
     r.l[FP_N - 1] = (uint32_t)acc;
     BLS_SET_VB(r, 2);
+    BLS_SET_LB(r, 0);        // limbs 0..12 non-negative and < 2^28
     return r;
 }
 
@@ -218,6 +235,7 @@ BLS_HD fp fp_sqr_core(const fp& a) {
     }
     r.l[FP_N - 1] = (uint32_t)acc;
     BLS_SET_VB(r, 2);
+    BLS_SET_LB(r, 0);
     return r;
 }
 
@@ -249,6 +267,7 @@ __device__ __forceinline__ fp fp_mul(const fp& a, const fp& b) {
 __host__ __device__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
 #if defined(BLS_TRACK_BOUNDS)
     BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(b) <= 2048, "fp_mul value bounds");
+    BLS_REQUIRE(BLS_LB(a) <= 2 && BLS_LB(b) <= 2, "fp_mul limb-unit bounds");
     const int64_t LIM = (1ll << 29) + (1ll << 20);     // limb-wise sum of two semi-normalised values, not three
     for (int i = 0; i < FP_N; i++) {
         int64_t x = (int32_t)a.l[i], y = (int32_t)b.l[i];
@@ -260,6 +279,7 @@ __host__ __device__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
 __host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
 #if defined(BLS_TRACK_BOUNDS)
     BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(a) <= 2048, "fp_sqr value bounds");
+    BLS_REQUIRE(BLS_LB(a) <= 2, "fp_sqr limb-unit bounds");
     for (int i = 0; i < FP_N; i++) {
         int64_t x = (int32_t)a.l[i];
         BLS_REQUIRE(x > -(1ll << 29) - (1ll << 20) && x < (1ll << 29) + (1ll << 20), "fp_sqr limb bound");
@@ -284,6 +304,7 @@ BLS_HD fp fp_carry_full(const fp& a) {
     }
     r.l[FP_N - 1] = a.l[FP_N - 1] + c;
     BLS_SET_VB(r, BLS_VB(a));
+    BLS_SET_LB(r, 0);
     return r;
 }
 
@@ -291,7 +312,7 @@ BLS_HD fp fp_carry_full(const fp& a) {
 // 106513.18; reciprocal 2^40 / that).  Any |a| <= 1024p in, |r| < 0.51p out, limbs fully carried.
 // ~50 instructions: the cheap way to stop value bounds from growing through chains of additions.
 BLS_HD fp fp_reduce(const fp& a) {
-    BLS_REQUIRE(BLS_VB(a) <= 1024, "fp_reduce bound");
+    BLS_REQUIRE(BLS_VB(a) <= 1024 && BLS_LB(a) <= 7, "fp_reduce bound");
     const int64_t RECIP = 10322735;                       // round(2^40 / (p / 2^364))
     int32_t top = (int32_t)a.l[FP_N - 1] + ((int32_t)a.l[FP_N - 2] >> 28);
     int32_t q = (int32_t)(((int64_t)top * RECIP + (1ll << 39)) >> 40);
@@ -306,6 +327,7 @@ BLS_HD fp fp_reduce(const fp& a) {
     acc += (int64_t)(int32_t)a.l[FP_N - 1] - (int64_t)q * (int32_t)k::P[FP_N - 1];
     r.l[FP_N - 1] = (uint32_t)acc;
     BLS_SET_VB(r, 1);
+    BLS_SET_LB(r, 0);
     return r;
 }
 
@@ -334,6 +356,7 @@ BLS_HD fp fp_canon(const fp& a) {
     }
     u.l[FP_N - 1] = r.l[FP_N - 1] + (neg ? k::P[FP_N - 1] : 0u) + c;
     BLS_SET_VB(u, 1);
+    BLS_SET_LB(u, 0);
     return u;
 }
 BLS_HD fp fp_canon_lt2p(const fp& t) { return fp_canon(t); }
@@ -364,6 +387,7 @@ BLS_HD fp fp_relimb_from32(const uint32_t (&w)[12]) {
         r.l[i] = (uint32_t)v & FP_MASK;
     }
     BLS_SET_VB(r, 16);      // any 384-bit integer is < 16p (2^384 / p < 10)
+    BLS_SET_LB(r, 0);
     return r;
 }
 BLS_HD void fp_relimb_to32(uint32_t (&w)[12], const fp& a) {   // a fully carried, < 2^384
@@ -462,6 +486,8 @@ BLS_HD fp2 fp2_from_const(const uint32_t (&c)[2 * FP_N]) {
     }
     BLS_SET_VB(r.c0, 1);
     BLS_SET_VB(r.c1, 1);
+    BLS_SET_LB(r.c0, 1);
+    BLS_SET_LB(r.c1, 1);
     return r;
 }
 
@@ -476,6 +502,10 @@ BLS_HD fp2 fp2_add(const fp2& a, const fp2& b) { return fp2{fp_add(a.c0, b.c0), 
 BLS_HD fp2 fp2_sub(const fp2& a, const fp2& b) { return fp2{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
 BLS_HD fp2 fp2_neg(const fp2& a) { return fp2{fp_neg(a.c0), fp_neg(a.c1)}; }
 BLS_HD fp2 fp2_dbl(const fp2& a) { return fp2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
+BLS_HD fp2 fp2_add_nc(const fp2& a, const fp2& b) { return fp2{fp_add_nc(a.c0, b.c0), fp_add_nc(a.c1, b.c1)}; }
+BLS_HD fp2 fp2_sub_nc(const fp2& a, const fp2& b) { return fp2{fp_sub_nc(a.c0, b.c0), fp_sub_nc(a.c1, b.c1)}; }
+BLS_HD fp2 fp2_dbl_nc(const fp2& a) { return fp2{fp_dbl_nc(a.c0), fp_dbl_nc(a.c1)}; }
+BLS_HD fp2 fp2_carry(const fp2& a) { return fp2{fp_carry(a.c0), fp_carry(a.c1)}; }
 BLS_HD fp2 fp2_conj(const fp2& a) { return fp2{a.c0, fp_neg(a.c1)}; }
 BLS_HD fp2 fp2_mul3(const fp2& a) { return fp2_add(fp2_dbl(a), a); }
 BLS_HD fp2 fp2_reduce(const fp2& a) { return fp2{fp_reduce(a.c0), fp_reduce(a.c1)}; }
@@ -485,7 +515,8 @@ BLS_HD fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp t0 = fp_mul(a.c0, b.c0);
     fp t1 = fp_mul(a.c1, b.c1);
     fp s = fp_mul(fp_add_nc(a.c0, a.c1), fp_add_nc(b.c0, b.c1));
-    return fp2{fp_sub(t0, t1), fp_sub(fp_sub(s, t0), t1)};
+    // t0 - t1: non-negative limbs on both sides, no carry; s - t0 - t1: one carry for two subtractions
+    return fp2{fp_sub_pos(t0, t1), fp_carry(fp_sub_nc(fp_sub_pos(s, t0), t1))};
 }
 
 // complex squaring: 2 base multiplications

@@ -20,6 +20,8 @@ BLS_HD fp6 fp6_dbl(const fp6& a) { return fp6{fp2_dbl(a.a0), fp2_dbl(a.a1), fp2_
 BLS_HD fp6 fp6_mul_by_v(const fp6& a) { return fp6{fp2_mul_xi(a.a2), a.a0, a.a1}; }
 // partial reduction of every coefficient (|v| < 0.51p): Fp12-level results are stored reduced so that value
 // bounds never accumulate across the Karatsuba layers
+BLS_HD fp6 fp6_add_nc(const fp6& a, const fp6& b) { return fp6{fp2_add_nc(a.a0, b.a0), fp2_add_nc(a.a1, b.a1), fp2_add_nc(a.a2, b.a2)}; }
+BLS_HD fp6 fp6_sub_nc(const fp6& a, const fp6& b) { return fp6{fp2_sub_nc(a.a0, b.a0), fp2_sub_nc(a.a1, b.a1), fp2_sub_nc(a.a2, b.a2)}; }
 BLS_HD fp6 fp6_reduce(const fp6& a) { return fp6{fp2_reduce(a.a0), fp2_reduce(a.a1), fp2_reduce(a.a2)}; }
 
 // 6 fp2 multiplications
@@ -40,9 +42,10 @@ BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
 BLS_MID fp6 fp6_mul_by_01(const fp6& a, const fp2& l0, const fp2& l1) {
     fp2 t0 = fp2_mul(a.a0, l0);
     fp2 t1 = fp2_mul(a.a1, l1);
-    fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.a0, a.a1), fp2_add(l0, l1)), t0), t1);
-    fp2 c0 = fp2_add(t0, fp2_mul_xi(fp2_mul(a.a2, l1)));
-    fp2 c2 = fp2_add(t1, fp2_mul(a.a2, l0));
+    // results keep at most 2 limb units (c1 is carried): the caller sums them limb-wise and reduces once
+    fp2 c1 = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add(a.a0, a.a1), fp2_add(l0, l1)), t0), t1));
+    fp2 c0 = fp2_add_nc(t0, fp2_mul_xi(fp2_mul(a.a2, l1)));
+    fp2 c2 = fp2_add_nc(t1, fp2_mul(a.a2, l0));
     return fp6{c0, c1, c2};
 }
 
@@ -95,8 +98,8 @@ BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     fp6 t0 = fp6_mul_by_01(f.c0, l.l0, l.l1);
     fp6 t1 = fp6_mul_by_1(f.c1, l.l2);
     fp6 s = fp6_mul_by_01(fp6_add(f.c0, f.c1), l.l0, fp2_add(l.l1, l.l2));
-    fp6 c1 = fp6_sub(fp6_sub(s, t0), t1);
-    fp6 c0 = fp6_add(t0, fp6_mul_by_v(t1));
+    fp6 c1 = fp6_sub_nc(fp6_sub_nc(s, t0), t1);            // 2 + 2 + 1 limb units
+    fp6 c0 = fp6_add_nc(t0, fp6_mul_by_v(t1));             // 2 + 1
     return fp12{fp6_reduce(c0), fp6_reduce(c1)};
 }
 
