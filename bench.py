@@ -12,6 +12,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -59,18 +60,16 @@ def main():
 
     ge.build()
     m = ge.load_package()
-    import c_oracle as co      # checker / input generator / CPU baseline only
 
     n = a.batch
-    ncores = os.cpu_count() or 1
-    distinct = n if ncores >= 16 else min(n, 8192)
     t0 = time.time()
-    recs = co.make_batch(distinct, seed=rank * n)         # valid (pk, SHA256("msg"+i), sig) tuples, host cores
-    if distinct < n:
-        recs = (recs * ((n + distinct - 1) // distinct))[:320 * n]
+    # n distinct valid (pk, SHA256("msg"+i), sig) tuples made by the library's own device signer
+    # (mi355_bls_sign_sets_device; parity-tested against the oracle in tests/test_gpu_sign.py)
+    gen = m.BatchedBLSVerifierCache.init(max_sets=n, device=local)
+    d_sets = sign_records(m, gen, dev, range(rank * n, rank * n + n))
+    del gen
     gen_s = time.time() - t0
-    d_sets = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
-    rnd = bytearray(co_sha256(co, b"Mr F was here"))
+    rnd = bytearray(hashlib.sha256(b"Mr F was here").digest())
 
     n_total = n * world
     nthreads = m.DEFAULT_NUM_THREADS * world                # global number of blinding chains
@@ -171,9 +170,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic: %d valid (pk, SHA256('msg'+i), sig) tuples per GPU%s, rnd=SHA256('Mr F was here'), resident in HBM"
-                    % (n, "" if distinct == n else " (%d distinct, tiled)" % distinct),
+            "dtype": "int64",
+            "data": "synthetic: %d distinct valid (pk, SHA256('msg'+i), sig) tuples per GPU (made by the device signer), "
+                    "rnd=SHA256('Mr F was here'), resident in HBM" % n,
             "config": {"workload": "BatchedBLSVerifier batchVerify, %d-tuple batch per GPU" % n, "global_batch": n_total,
                        "blinding_chains": nthreads, "parallelism": "shard%d" % world, "batches_in_flight": inflight},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -187,8 +186,9 @@ def main():
         }
         out["roofline"]["traffic"] = pmc_traffic(dom)
         if not a.no_aux:
-            out["aux"] = aux_rows(m, co, cache, dev)
+            out["aux"] = aux_rows(m, cache, dev)
         if not a.no_cpu:
+            import c_oracle as co      # the CPU restatement: this leg only
             out["cpu_baseline"] = cpu_baseline(co, a.cpu_sample, bytes(rnd))
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
@@ -211,17 +211,41 @@ def pmc_traffic(stage):
         return None
 
 
-def aux_rows(m, co, cache, dev):
+R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def secret_key(i):
+    """Deterministic synthetic secret scalar in [1, r)."""
+    return int.from_bytes(hashlib.sha256(b"sk" + i.to_bytes(8, "little")).digest(), "little") % (R_ORDER - 1) + 1
+
+
+def sign_records(m, cache, dev, ids, sks=None, msgs=None):
+    """SignatureSet records resident in HBM: tuple i = (pk_i, SHA256("msg"+i), sig_i) (the generator of
+    benchmarks/bls_signature.nim:258-268), produced by the device signer."""
+    ids = list(ids)
+    sks = sks if sks is not None else [secret_key(i) for i in ids]
+    msgs = msgs if msgs is not None else [hashlib.sha256(b"msg" + str(i).encode()).digest() for i in ids]
+    d_sk = torch.frombuffer(bytearray(b"".join(s.to_bytes(32, "little") for s in sks)), dtype=torch.uint8).to(dev)
+    d_ms = torch.frombuffer(bytearray(b"".join(msgs)), dtype=torch.uint8).to(dev)
+    d_out = torch.zeros(320 * len(ids), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    ok, _ = m.signSets_device(cache, d_sk.data_ptr(), d_ms.data_ptr(), len(ids), d_out.data_ptr())
+    assert ok
+    return d_out
+
+
+def aux_rows(m, cache, dev):
     """Side measurements of the other BASELINE.json configs (not the headline metric):
     config 3 fastAggregateVerify with 32 768 keys, config 4 G1 Pippenger MSM with 2^20 points."""
     import random
     import numpy as np
     out = {}
     n = 32768
-    pks, sksum = co.make_pks(n, seed=1 << 41)
-    msg = b"Mr F was here"
-    sig = co.g2_mul(co.hash_to_g2(msg, b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"), sksum)
-    d_pks = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    msg = hashlib.sha256(b"Mr F was here").digest()
+    sks = [secret_key((1 << 41) + i) for i in range(n)]
+    d_pks = sign_records(m, cache, dev, range(n), sks=sks, msgs=[msg] * n).view(n, 320)[:, :96].contiguous()
+    # the aggregate signature of the n signers on msg is [sum sk_i mod r]H(msg): one more signer call
+    sig = bytes(sign_records(m, cache, dev, [0], sks=[sum(sks) % R_ORDER], msgs=[msg]).cpu().numpy())[128:320]
     fav = lambda: m._check(m.lib().mi355_bls_fast_aggregate_verify_device(cache._h, d_pks.data_ptr(), n, msg, len(msg), sig, 0))
     assert fav() == 1
     t0 = time.perf_counter()
@@ -233,10 +257,9 @@ def aux_rows(m, co, cache, dev):
                                         "note": "one pairing per call: latency-bound (single-lane hash-to-G2 + 2-pair Miller loop + final exponentiation)"}
     nm = 1 << 20
     rng = random.Random(7)
-    base = [co.sk_to_pk(rng.getrandbits(96) | 1) for _ in range(2048)]
-    pts = b"".join(base[i % 2048] for i in range(nm))
+    base = sign_records(m, cache, dev, range(2048), sks=[rng.getrandbits(96) | 1 for _ in range(2048)], msgs=[msg] * 2048)
+    dp = base.view(2048, 320)[:, :96].contiguous().repeat(nm // 2048, 1).reshape(-1)     # P_i = [a_i]G1, a_i 96-bit
     sc = np.random.default_rng(7).integers(0, 256, size=(nm, 32), dtype=np.uint8).tobytes()
-    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
     ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
     m.p1s_mult_pippenger_device(cache, dp.data_ptr(), nm, ds.data_ptr(), 255)
     t0 = time.perf_counter()
@@ -246,12 +269,6 @@ def aux_rows(m, co, cache, dev):
     out["g1_msm_2^20"] = {"points_per_s": nm / dt, "ms_per_call": dt * 1e3, "nbits": 255,
                           "GBs_at_128B_per_point": 128.0 * nm / dt / 1e9}
     return out
-
-
-def co_sha256(co, b):
-    o = ctypes.create_string_buffer(32)
-    co.lib().oracle_sha256(b, len(b), o)
-    return o.raw
 
 
 def cpu_baseline(co, sample, rnd):

@@ -144,6 +144,17 @@ int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks
 int mi355_bls_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n,
                                const void* sig);
 
+/* Batch signer / input generator.  Per tuple i, from a 32-byte little-endian secret scalar
+ * (blst_scalar image, SecretKey, blst_min_pubkey_sig_core.nim:43-66) and a 32-byte message:
+ *   publicFromSecret (core :118-133): sk == 0 or sk >= r -> status[i] = 1 and a zeroed record; pk = affine([sk]G1)
+ *   coreSign (core :230-251) with the signature DST (bls_sig_min_pubkey.nim:31): sig = affine([sk]H(msg))
+ * written as the 320-byte SignatureSet record (pk, msg, sig).  Returns 1 when every key was valid, 0 otherwise.
+ * The scalar multiplications are VARIABLE TIME: this exists to synthesise test and bench inputs (the reference
+ * does the same with sign() in benchmarks/bls_signature.nim:258-268), never to sign with real keys. */
+int mi355_bls_sign_sets(mi355_bls_ctx* ctx, const uint8_t* sks32, const uint8_t* msgs32, size_t n, void* out_sets, uint8_t* status);
+int mi355_bls_sign_sets_device(mi355_bls_ctx* ctx, const void* d_sks32, const void* d_msgs32, size_t n, void* d_out_sets, void* stream,
+                               uint8_t* status);
+
 /* Stage outputs of the LAST batch call on this context, for parity tests (no reference
  * counterpart: BLST keeps these inside blst_pairing).  `what`:
  *   0: blinding scalars r_i           n x 8 B  (LE u64)

@@ -71,6 +71,8 @@ def lib():
         L.mi355_bls_last_deser_ms.argtypes = [vp]
         L.mi355_bls_last_deser_ms.restype = ctypes.c_float
         L.mi355_bls_combine.argtypes = [vp, cp, cp, cp, sz, cp, cp]
+        L.mi355_bls_sign_sets.argtypes = [vp, cp, cp, sz, vp, vp]
+        L.mi355_bls_sign_sets_device.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.mi355_bls_aggregate_verify.argtypes = [vp, cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -265,6 +267,30 @@ def batchVerifyCompressed(cache, pubkeys, messages, signatures, secureRandomByte
     st = ctypes.create_string_buffer(n)
     ok = _check(lib().mi355_bls_batch_verify_compressed(cache._h, pk, ms, sg, n, bytes(secureRandomBytes), st))
     return bool(ok), st.raw
+
+
+def signSets(cache, secret_keys, messages):
+    """Batch signer / input generator: per tuple publicFromSecret + coreSign
+    (blst_min_pubkey_sig_core.nim:118-133, :230-251) on the device, VARIABLE TIME (test and bench inputs only).
+    secret_keys: n x 32-byte little-endian scalars, messages: n x 32 bytes (lists or concatenated).
+    -> (all_valid, n x 320-byte SignatureSet records, per-tuple status bytes: 1 = sk == 0 or sk >= r)."""
+    sk = secret_keys if isinstance(secret_keys, (bytes, bytearray)) else b"".join(bytes(x) for x in secret_keys)
+    ms = messages if isinstance(messages, (bytes, bytearray)) else b"".join(bytes(x) for x in messages)
+    assert len(sk) % 32 == 0 and len(ms) == len(sk)
+    n = len(sk) // 32
+    if n == 0:
+        return True, b"", b""
+    out = ctypes.create_string_buffer(320 * n)
+    st = ctypes.create_string_buffer(n)
+    ok = _check(lib().mi355_bls_sign_sets(cache._h, bytes(sk), bytes(ms), n, out, st))
+    return bool(ok), out.raw, st.raw
+
+
+def signSets_device(cache, d_sks, d_msgs, n, d_out, stream=0):
+    """Same with the scalars, messages and the output records resident in device memory (raw pointers)."""
+    st = ctypes.create_string_buffer(max(n, 1))
+    ok = _check(lib().mi355_bls_sign_sets_device(cache._h, d_sks, d_msgs, n, d_out, stream, st))
+    return bool(ok), st.raw[:n]
 
 
 class MultiSignatureSet:

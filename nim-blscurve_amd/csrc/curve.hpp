@@ -172,6 +172,27 @@ BLS_HDN jac<F> jac_mul_u64_jac(const jac<F>& p, uint64_t kk) {
     return acc;
 }
 
+// [k]P for a 256-bit scalar (8 little-endian words).  NOT constant time: only the bench/test input generator
+// (k_sign_*) uses it, never a production signer.
+template <class F>
+BLS_HDN jac<F> jac_mul_256(const aff<F>& p, const uint32_t (&kk)[8]) {
+    jac<F> acc = jac_inf<F>();
+    for (int i = 255; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((kk[i >> 5] >> (i & 31)) & 1) acc = jac_add_aff(acc, p);
+    }
+    return acc;
+}
+template <class F>
+BLS_HDN jac<F> jac_mul_256_jac(const jac<F>& p, const uint32_t (&kk)[8]) {
+    jac<F> acc = jac_inf<F>();
+    for (int i = 255; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((kk[i >> 5] >> (i & 31)) & 1) acc = jac_add(acc, p);
+    }
+    return acc;
+}
+
 BLS_HD g1_aff g1_aff_load(const uint8_t* p) { return g1_aff{fp_load_le(p), fp_load_le(p + 48)}; }
 BLS_HD g2_aff g2_aff_load(const uint8_t* p) { return g2_aff{fp2_load_le(p), fp2_load_le(p + 96)}; }
 BLS_HD void g1_jac_store(uint8_t* p, const g1_jac& a) {

@@ -948,6 +948,55 @@ __global__ void __launch_bounds__(WAVE) k_aggv_setup(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Batch signer / input generator: per tuple publicFromSecret (core :118-133:
+// sk == 0 or sk >= r -> false; pk = affine([sk]G1)) and coreSign (core :230-251: sig = affine([sk]H(msg))),
+// written as a SignatureSet record.  Variable-time scalar multiplication: test/bench input generation only.
+// ------------------------------------------------------------------------------------------
+BLS_HD bool sk_load_check(uint32_t (&kk)[8], const uint8_t* sk) {
+    uint32_t any = 0, borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        kk[j] = (uint32_t)sk[4 * j] | ((uint32_t)sk[4 * j + 1] << 8) | ((uint32_t)sk[4 * j + 2] << 16) | ((uint32_t)sk[4 * j + 3] << 24);
+        any |= kk[j];
+        uint64_t d = (uint64_t)kk[j] - k::R_ORDER[j] - borrow;
+        borrow = (uint32_t)(d >> 63);
+    }
+    return any != 0 && borrow != 0;                                  // 0 < sk < r
+}
+__global__ void __launch_bounds__(WAVE) k_sign_pk(const uint8_t* __restrict__ sks, const uint8_t* __restrict__ msgs, uint32_t n, uint8_t* __restrict__ sets,
+                                                  uint8_t* __restrict__ status, uint32_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    uint32_t kk[8];
+    bool ok = sk_load_check(kk, sks + (size_t)i * 32);
+    status[i] = ok ? 0 : 1;
+    if (!ok) atomicOr(flags + 2, 1u);
+    uint32_t* o = reinterpret_cast<uint32_t*>(sets + (size_t)i * 320);
+    g1_aff g{fp_from_const(k::G1_X), fp_from_const(k::G1_Y)};
+    g1_jac a = jac_mul_256(g, kk);
+    fp zi = fp_inv(a.z), zi2 = fp_sqr(zi);                           // z != 0 for 0 < sk < r
+    fp x = fp_select(ok, fp_mul(a.x, zi2), fp_zero()), y = fp_select(ok, fp_mul(a.y, fp_mul(zi2, zi)), fp_zero());
+    st_fp_blst(o, x); st_fp_blst(o + 12, y);
+    const uint8_t* m = msgs + (size_t)i * 32;
+    for (int j = 0; j < 8; j++) o[24 + j] = (uint32_t)m[4 * j] | ((uint32_t)m[4 * j + 1] << 8) | ((uint32_t)m[4 * j + 2] << 16) | ((uint32_t)m[4 * j + 3] << 24);
+}
+__global__ void __launch_bounds__(WAVE) k_sign_sig(const uint8_t* __restrict__ sks, const uint8_t* __restrict__ msgs, uint32_t n, dst_t dst,
+                                                   uint8_t* __restrict__ sets) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    uint32_t kk[8];
+    bool ok = sk_load_check(kk, sks + (size_t)i * 32);
+    uint8_t msg[32];
+    for (int j = 0; j < 32; j++) msg[j] = msgs[(size_t)i * 32 + j];
+    g2_jac h = hash_to_g2(msg, 32, dst.b, dst.len);
+    g2_jac a = jac_mul_256_jac(h, kk);
+    fp2 zi = fp2_inv(a.z), zi2 = fp2_sqr(zi);
+    fp2 x = fp2_select(ok, fp2_mul(a.x, zi2), fp2_zero()), y = fp2_select(ok, fp2_mul(a.y, fp2_mul(zi2, zi)), fp2_zero());
+    uint32_t* o = reinterpret_cast<uint32_t*>(sets + (size_t)i * 320) + 32;
+    st_fp_blst(o, x.c0); st_fp_blst(o + 12, x.c1); st_fp_blst(o + 24, y.c0); st_fp_blst(o + 36, y.c1);
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1594,6 +1643,50 @@ extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t
 }
 
 extern "C" float mi355_bls_last_deser_ms(mi355_bls_ctx* c) { return c ? c->deser_ms : 0.f; }
+
+// ------------------------------------------------------------------------------------------
+// Batch signer (test / bench input generation)
+// ------------------------------------------------------------------------------------------
+extern "C" int mi355_bls_sign_sets_device(mi355_bls_ctx* c, const void* d_sks32, const void* d_msgs32, size_t n, void* d_out_sets, void* stream,
+                                          uint8_t* status) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 1;
+    if (!d_sks32 || !d_msgs32 || !d_out_sets) return MI355_BLS_ERR_ARG;
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    uint32_t nb = ((uint32_t)n + WAVE - 1) / WAVE;
+    k_sign_pk<<<nb, WAVE, 0, st>>>((const uint8_t*)d_sks32, (const uint8_t*)d_msgs32, (uint32_t)n, (uint8_t*)d_out_sets, c->d_status, c->d_flags);
+    k_sign_sig<<<nb, WAVE, 0, st>>>((const uint8_t*)d_sks32, (const uint8_t*)d_msgs32, (uint32_t)n, c->dst, (uint8_t*)d_out_sets);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    uint32_t fl[4];
+    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    HIPCHK(hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]));
+    c->timings[7] = c->timings[0];
+    return fl[2] ? 0 : 1;
+}
+
+extern "C" int mi355_bls_sign_sets(mi355_bls_ctx* c, const uint8_t* sks32, const uint8_t* msgs32, size_t n, void* out_sets, uint8_t* status) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 1;
+    if (!sks32 || !msgs32 || !out_sets) return MI355_BLS_ERR_ARG;
+    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_comp, sks32, n * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 48, msgs32, n * 32, hipMemcpyHostToDevice, nullptr));
+    int rc = mi355_bls_sign_sets_device(c, c->d_comp, c->d_comp + c->cap * 48, n, c->d_sets, nullptr, status);
+    if (rc < 0) return rc;
+    HIPCHK(hipMemcpy(out_sets, c->d_sets, n * 320, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemsetAsync(c->d_comp, 0, n * 32, nullptr));          // do not leave the scalars in the staging buffer
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------
 // combine

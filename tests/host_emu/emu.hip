@@ -28,6 +28,16 @@ void emu_iso3(const uint8_t* in, uint8_t* out) { g2_jac_store(out, iso3_g2(g2_ja
 void emu_hash_to_g2(const uint8_t* m, uint32_t n, const uint8_t* dst, uint32_t dn, uint8_t* out) { g2_jac_store(out, hash_to_g2(m, n, dst, dn)); }
 void emu_g1_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g1_jac_store(out, jac_mul_u64(g1_aff_load(p), k)); }
 void emu_g2_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g2_jac_store(out, jac_mul_u64(g2_aff_load(p), k)); }
+void emu_g1_mul_256(const uint8_t* p, const uint8_t* k32, uint8_t* out) {
+    uint32_t kk[8];
+    for (int j = 0; j < 8; j++) kk[j] = (uint32_t)k32[4 * j] | ((uint32_t)k32[4 * j + 1] << 8) | ((uint32_t)k32[4 * j + 2] << 16) | ((uint32_t)k32[4 * j + 3] << 24);
+    g1_jac_store(out, jac_mul_256(g1_aff_load(p), kk));
+}
+void emu_g2_mul_256_jac(const uint8_t* p, const uint8_t* k32, uint8_t* out) {
+    uint32_t kk[8];
+    for (int j = 0; j < 8; j++) kk[j] = (uint32_t)k32[4 * j] | ((uint32_t)k32[4 * j + 1] << 8) | ((uint32_t)k32[4 * j + 2] << 16) | ((uint32_t)k32[4 * j + 3] << 24);
+    g2_jac_store(out, jac_mul_256_jac(g2_jac_load(p), kk));
+}
 void emu_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g1_jac_store(out, jac_add(g1_jac_load(a), g1_jac_load(b))); }
 void emu_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g2_jac_store(out, jac_add(g2_jac_load(a), g2_jac_load(b))); }
 // n pairs of (P Jacobian 144 B, Q Jacobian 288 B) -> final_exp(miller) 576 B

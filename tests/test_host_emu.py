@@ -64,6 +64,13 @@ def test_scalar_mul_and_add(emu):
         assert g1_jac_to_affine(r1) == o.g1_mul(p, kk)
         r2 = call(emu, "emu_g2_mul_u64", o.g2_to_blst_affine(q), ctypes.c_uint64(kk), outlen=288)
         assert g2_jac_to_affine(r2) == o.g2_mul(q, kk)
+    # 256-bit scalars (batch signer): affine base in G1, Jacobian base in G2
+    for kk in [1, o.R - 1, rng.randrange(o.R), (1 << 255) + 12345]:
+        k32 = kk.to_bytes(32, "little")
+        r1 = call(emu, "emu_g1_mul_256", o.g1_to_blst_affine(p), k32, outlen=144)
+        assert g1_jac_to_affine(r1) == o.g1_mul(p, kk)
+        r2 = call(emu, "emu_g2_mul_256_jac", g2_aff_to_jac_bytes(q), k32, outlen=288)
+        assert g2_jac_to_affine(r2) == o.g2_mul(q, kk)
     # complete addition: P+P, P+(-P), inf+P, P+inf
     pj, qj = g1_aff_to_jac_bytes(p), g2_aff_to_jac_bytes(q)
     assert g1_jac_to_affine(call(emu, "emu_g1_add", pj, pj, outlen=144)) == o.g1_add(p, p)
