@@ -667,19 +667,20 @@ struct msm_win {
 __device__ __forceinline__ uint32_t msm_win_off(const msm_win& W, uint32_t w) {
     return w < W.wrem ? w * (W.wbase + 1) : W.wrem * (W.wbase + 1) + (w - W.wrem) * W.wbase;
 }
-__device__ __forceinline__ uint32_t msm_digit(const uint8_t* __restrict__ sc, size_t i, uint32_t w, const msm_win& W) {
+// scalars are little-endian, sbytes bytes each (32: blst_scalar images; 8: the u64 blinding scalars)
+__device__ __forceinline__ uint32_t msm_digit(const uint8_t* __restrict__ sc, size_t i, uint32_t w, const msm_win& W, uint32_t sbytes) {
     uint32_t bit0 = msm_win_off(W, w);
     uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase;
-    const uint8_t* p = sc + i * 32;
+    const uint8_t* p = sc + i * sbytes;
     uint32_t byte0 = bit0 >> 3;
     uint64_t v = 0;
-    for (uint32_t j = 0; j < 4 && byte0 + j < 32; j++) v |= (uint64_t)p[byte0 + j] << (8 * j);
+    for (uint32_t j = 0; j < 4 && byte0 + j < sbytes; j++) v |= (uint64_t)p[byte0 + j] << (8 * j);
     return (uint32_t)(v >> (bit0 & 7)) & ((1u << len) - 1u);
 }
-__global__ void __launch_bounds__(WAVE) k_msm_hist(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(WAVE) k_msm_hist(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, msm_win W, uint32_t c, uint32_t* __restrict__ hist) {
     uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;       // lane per (point, window)
     if (i >= n) return;
-    uint32_t d = msm_digit(sc, i, w, W);
+    uint32_t d = msm_digit(sc, i, w, W, sbytes);
     if (d) atomicAdd(&hist[((size_t)w << c) | d], 1u);
 }
 // one wave per window
@@ -701,11 +702,11 @@ __global__ void __launch_bounds__(WAVE) k_msm_scan(const uint32_t* __restrict__ 
         run += h[b];
     }
 }
-__global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict__ sc, uint32_t n, msm_win W, uint32_t c,
+__global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, msm_win W, uint32_t c,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
     uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
     if (i >= n) return;
-    uint32_t d = msm_digit(sc, i, w, W);
+    uint32_t d = msm_digit(sc, i, w, W, sbytes);
     if (d) {
         uint32_t pos = atomicAdd(&cursor[((size_t)w << c) | d], 1u);
         sorted[(size_t)w * n + pos] = i;
@@ -837,6 +838,82 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
         uint32_t sh = msm_win_off(W, w);
         for (uint32_t i = 0; i < sh; i++) acc = jac_dbl(acc);
         st_g1_int(winout + (size_t)w * G1W, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Signature side of large batches: bucket fold + bilinearity instead of n 64-bit scalar multiplications.
+//   e(-G1, sum_i [r_i]S_i) = prod_{w,d} e(-[d 2^(cw)]G1, B_{w,d}),   B_{w,d} = sum of the S_i whose w-th c-bit
+//   digit of r_i is d  (r_i = sum_w d_{i,w} 2^(cw)).
+// The 64/c x 2^c bucket sums B (counting sort by digit, then mixed additions only: 64/c per tuple instead of
+// 64 doublings + ~32 additions) become 64/c x 2^c EXTRA MILLER PAIRS against constant G1 points, so no
+// bucket reduction, window doubling chain or other serial tail is needed at all.  The verdict and the
+// final-exponentiated GT value are unchanged; sum [r_i]S_i itself (BLST's AggrSign, fetch_stage 3) is folded
+// from the buckets only on demand (k_sig_fold).
+// ------------------------------------------------------------------------------------------
+// signatures converted once from the blst image to the device representation: internal AoS, 4 x FPW words
+__global__ void __launch_bounds__(WAVE) k_sig_convert(const uint8_t* __restrict__ sets, uint32_t n, uint32_t* __restrict__ pts_int) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    g2_aff q = ld_g2a_blst(reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 128));
+    uint32_t* o = pts_int + (size_t)i * 4 * FPW;
+    st_fp_int(o, q.x.c0); st_fp_int(o + FPW, q.x.c1); st_fp_int(o + 2 * FPW, q.y.c0); st_fp_int(o + 3 * FPW, q.y.c1);
+}
+// slot g = (w << c) | d  ->  -[d 2^(cw)]G1 (Jacobian, internal AoS); d = 0 gives infinity (pair skipped)
+__global__ void __launch_bounds__(WAVE) k_sig_consts(uint32_t c, uint32_t total, uint32_t* __restrict__ out) {
+    uint32_t g = blockIdx.x * WAVE + threadIdx.x;
+    if (g >= total) return;
+    uint64_t sc = (uint64_t)(g & ((1u << c) - 1u)) << (c * (g >> c));
+    g1_aff ng{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y)};
+    st_g1_int(out + (size_t)g * G1W, jac_mul_u64(ng, sc));
+}
+// L lanes (a power of two <= 64) per bucket slot: lane s adds entries s, s+L, ... of the bucket's sorted list,
+// then the L partial sums are folded with wave shuffles.  Result -> Miller pair n + g = (consts[g], B_g).
+__global__ void __launch_bounds__(WAVE) k_sig_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+                                                     const uint32_t* __restrict__ hist, uint32_t n, uint32_t c, uint32_t lshift, uint32_t total,
+                                                     const uint32_t* __restrict__ consts, uint4* __restrict__ H, uint4* __restrict__ P, size_t stride) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    uint32_t L = 1u << lshift, g = t >> lshift, s = t & (L - 1);
+    g2_jac acc = jac_inf<fp2>();
+    if (g < total) {
+        uint32_t w = g >> c, cnt = hist[g], off = offs[g];
+        const uint32_t* srt = sorted + (size_t)w * n + off;
+        for (uint32_t j = s; j < cnt; j += L) {
+            const uint32_t* pw = pts + (size_t)srt[j] * (4 * FPW);
+            g2_aff q{fp2{ld_fp_int(pw), ld_fp_int(pw + FPW)}, fp2{ld_fp_int(pw + 2 * FPW), ld_fp_int(pw + 3 * FPW)}};
+            acc = jac_add_aff(acc, q);
+        }
+    }
+    for (uint32_t d = L >> 1; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, (int)d);
+        acc = jac_add(acc, o);
+    }
+    if (g < total && s == 0) {
+        soa_st_g2(H, stride, (size_t)n + g, acc);
+        soa_st_g1(P, stride, (size_t)n + g, ld_g1_int(consts + (size_t)g * G1W));
+    }
+}
+// On demand (fetch_stage 3): sum [r_i]S_i = sum_w 2^(cw) sum_d d B_{w,d}; lane w folds window w with running
+// sums, then a Horner pass over the windows.  One wave, slow, never on the verification path.
+__global__ void __launch_bounds__(WAVE) k_sig_fold(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t nwin, uint32_t c, uint32_t* __restrict__ agg_out) {
+    __shared__ uint32_t wsum[32 * G2W];
+    uint32_t w = threadIdx.x;
+    if (w < nwin) {
+        g2_jac S = jac_inf<fp2>(), T = jac_inf<fp2>();
+        for (uint32_t d = (1u << c) - 1; d >= 1; d--) {
+            S = jac_add(S, soa_ld_g2(H, stride, (size_t)n + ((w << c) | d)));
+            T = jac_add(T, S);
+        }
+        st_g2_int(wsum + (size_t)w * G2W, T);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g2_jac acc = ld_g2_int(wsum + (size_t)(nwin - 1) * G2W);
+        for (uint32_t j = nwin - 1; j-- > 0;) {
+            for (uint32_t i = 0; i < c; i++) acc = jac_dbl(acc);
+            acc = jac_add(acc, ld_g2_int(wsum + (size_t)j * G2W));
+        }
+        st_g2_blst(agg_out, acc);
     }
 }
 
@@ -1046,6 +1123,13 @@ struct mi355_bls_ctx {
     uint4* d_P = nullptr;
     uint4* d_lines = nullptr;
     uint32_t* d_spart = nullptr;
+    // bucket fold of the signatures (batches of >= SIG_BUCKET_MIN tuples)
+    uint32_t* d_sig_pts = nullptr;   // signatures in the device representation, cap x 4 x FPW words
+    uint32_t* d_sig_sorted = nullptr;// counting sort by digit: nwin x cap tuple indices
+    uint32_t* d_sig_hist = nullptr;  // 3 x SIG_SLOTS_MAX: histogram, offsets, cursors
+    uint32_t* d_sig_consts = nullptr;// -[d 2^(cw)]G1 for the window widths c = 4 and c = 8
+    uint32_t sig_c = 0, sig_slots = 0; // window width / bucket slots of the last batch (0: per-tuple multiplications)
+    bool agg_valid = false;
     uint32_t* d_agg = nullptr;
     uint32_t* d_agg1 = nullptr;      // G1 aggregate (blst_p1 image)
     uint8_t* d_msg = nullptr;        // message (<= 4096 B) + signature staging
@@ -1070,6 +1154,10 @@ struct mi355_bls_ctx {
     msm_ws* msm = nullptr;           // lazily sized MSM workspace
 };
 
+constexpr uint32_t SIG_SLOTS_MAX = 2048;     // 8 windows x 256 digits
+constexpr size_t SIG_BUCKET_MIN = 1024;      // below this the per-tuple 64-bit multiplications are cheaper than the extra pairs
+constexpr size_t SIG_WIDE_MIN = 40000;       // from here 8-bit digits (2048 extra pairs, 8 additions per tuple) beat 4-bit ones (256, 15)
+
 static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
 
 extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
@@ -1077,7 +1165,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -1107,7 +1195,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     c->device = device;
     c->msm = new msm_ws();
     c->cap = max_sets;
-    c->stride = ((max_sets + 1 + 63) / 64) * 64;
+    c->stride = ((max_sets + 1 + SIG_SLOTS_MAX + 63) / 64) * 64;          // tuple pairs + the extra pair(s) of the signature side
     std::memset(&c->dst, 0, sizeof(c->dst));
     c->dst.len = sizeof(DST_SIG) - 1;
     std::memcpy(c->dst.b, DST_SIG, c->dst.len);
@@ -1128,6 +1216,10 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_P, c->stride * 3 * 64);
     ALLOC(c->d_lines, c->stride * 6 * 64 * (size_t)N_LINES);
     ALLOC(c->d_spart, (nwaves + 16) * G2W * 4);
+    ALLOC(c->d_sig_pts, max_sets * 4 * FPW * 4);
+    ALLOC(c->d_sig_sorted, max_sets * 16 * 4);
+    ALLOC(c->d_sig_hist, 3 * SIG_SLOTS_MAX * 4);
+    ALLOC(c->d_sig_consts, 2 * SIG_SLOTS_MAX * G1W * 4);
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
     ALLOC(c->d_msg, 4096 + 192);
@@ -1148,6 +1240,9 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->slots = 4u * (uint32_t)prop.multiProcessorCount;
+    k_sig_consts<<<(256 + WAVE - 1) / WAVE, WAVE>>>(4, 256, c->d_sig_consts);
+    k_sig_consts<<<(2048 + WAVE - 1) / WAVE, WAVE>>>(8, 2048, c->d_sig_consts + (size_t)SIG_SLOTS_MAX * G1W);
+    HIPCHK(hipDeviceSynchronize());
     *out = c;
     return 0;
 }
@@ -1188,42 +1283,77 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[3], st));
-    k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, 320, 128, n32, c->d_r, c->d_spart);
-    if (nb > 64) {          // two-level fold: 16 waves, then one
-        uint32_t* part2 = c->d_spart + (size_t)nb * G2W;
-        k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
-        k_sigsum<<<1, WAVE, 0, st>>>(part2, 16, c->d_H, c->d_P, c->stride, n, c->d_agg);
-    } else {
-        k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
-    }
-    HIPCHK(hipEventRecord(c->ev[4], st));
-    // The n tuple pairs fill the chip's wave slots exactly at n = 64 * slots; the extra (AggrSign, -G1)
-    // pair would cost a whole second round, so its 68 lines are produced by one side-stream wave that
-    // runs beside k_lineprod (which is sized to leave a few slots free).
-    uint32_t nb1 = (n32 + 1 + WAVE - 1) / WAVE;
-    bool use_side = (nb1 + c->slots - 1) / c->slots > (nb + c->slots - 1) / c->slots;
-    if (use_side) {
-        k_lines<<<nb, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32, c->stride, c->d_lines);
+    uint32_t nblk_max = c->slots / N_LINES, npairs = n32, xpair = n32;
+    if (n >= SIG_BUCKET_MIN) {
+        // bucket fold: the signature side becomes sig_slots extra Miller pairs n .. n + sig_slots - 1
+        uint32_t cw = n >= SIG_WIDE_MIN ? 8 : 4, nwin = 64 / cw, total = nwin << cw;
+        msm_win W{nwin, cw, 0};
+        uint32_t *hist = c->d_sig_hist, *offs = hist + SIG_SLOTS_MAX, *cursor = offs + SIG_SLOTS_MAX;
+        HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, st));
+        k_sig_convert<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_sig_pts);
+        k_msm_hist<<<dim3(nb, nwin), WAVE, 0, st>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
+        k_msm_scan<<<nwin, WAVE, 0, st>>>(hist, cw, offs, cursor);
+        k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, st>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
+        uint32_t per = n32 >> cw, lshift = 0;                          // expected entries per bucket; ~16 per lane
+        while (lshift < 6 && (per >> (lshift + 1)) >= 16) lshift++;
+        k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
+                                                                             c->d_sig_consts + (cw == 8 ? (size_t)SIG_SLOTS_MAX * G1W : 0), c->d_H, c->d_P,
+                                                                             c->stride);
+        c->sig_c = cw;
+        c->sig_slots = total;
+        c->agg_valid = false;
+        npairs = n32 + total;
+        xpair = 0xffffffffu;
+        HIPCHK(hipEventRecord(c->ev[4], st));
+        k_lines<<<(npairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
         HIPCHK(hipEventRecord(c->ev[5], st));
-        HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
-        k_lines<<<1, WAVE, 0, c->side>>>(c->d_P, c->d_H, n32, 1, c->stride, c->d_lines);
-        HIPCHK(hipEventRecord(c->ev_side, c->side));
     } else {
-        k_lines<<<nb1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
-        HIPCHK(hipEventRecord(c->ev[5], st));
+        c->sig_c = 0;
+        c->sig_slots = 0;
+        c->agg_valid = true;
+        k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, 320, 128, n32, c->d_r, c->d_spart);
+        if (nb > 64) {          // two-level fold: 16 waves, then one
+            uint32_t* part2 = c->d_spart + (size_t)nb * G2W;
+            k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
+            k_sigsum<<<1, WAVE, 0, st>>>(part2, 16, c->d_H, c->d_P, c->stride, n, c->d_agg);
+        } else {
+            k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
+        }
+        HIPCHK(hipEventRecord(c->ev[4], st));
+        // The extra (AggrSign, -G1) pair goes through k_lineprod2; when it would cost the k_lines launch one
+        // more round of waves, its 68 lines are produced by one side-stream wave that runs beside k_lineprod
+        // (which is then sized to leave a few slots free).
+        uint32_t nb1 = (n32 + 1 + WAVE - 1) / WAVE;
+        bool use_side = (nb1 + c->slots - 1) / c->slots > (nb + c->slots - 1) / c->slots;
+        if (use_side) {
+            k_lines<<<nb, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32, c->stride, c->d_lines);
+            HIPCHK(hipEventRecord(c->ev[5], st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
+            k_lines<<<1, WAVE, 0, c->side>>>(c->d_P, c->d_H, n32, 1, c->stride, c->d_lines);
+            HIPCHK(hipEventRecord(c->ev_side, c->side));
+            // workgroups are dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first one:
+            // leave one free wave slot per XCD so the side-stream wave really runs beside k_lineprod
+            nblk_max = (c->slots > 8 ? c->slots - 8 : c->slots) / N_LINES;
+        } else {
+            k_lines<<<nb1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
+            HIPCHK(hipEventRecord(c->ev[5], st));
+        }
+        uint32_t nblk0 = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
+        uint32_t m0 = (n32 + WAVE * nblk0 - 1) / (WAVE * nblk0);
+        if (m0 < 1) m0 = 1;
+        nblk0 = (n32 + WAVE * m0 - 1) / (WAVE * m0);
+        k_lineprod<<<dim3(N_LINES, nblk0), WAVE, 0, st>>>(c->d_lines, n32, c->stride, m0, c->d_lpart, nblk0);
+        if (use_side) HIPCHK(hipStreamWaitEvent(st, c->ev_side, 0));
+        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk0, c->d_lines, c->stride, xpair, c->d_L);
     }
-    // workgroups are dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first one:
-    // leave one free wave slot per XCD so the side-stream wave really runs beside k_lineprod
-    uint32_t nblk = (c->slots > 8 ? c->slots - 8 : c->slots) / N_LINES;
-    if (!use_side) nblk = c->slots / N_LINES;
-    if (nblk < 1) nblk = 1;
-    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
-    uint32_t m = (n32 + WAVE * nblk - 1) / (WAVE * nblk);
-    if (m < 1) m = 1;
-    nblk = (n32 + WAVE * m - 1) / (WAVE * m);
-    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, n32, c->stride, m, c->d_lpart, nblk);
-    if (use_side) HIPCHK(hipStreamWaitEvent(st, c->ev_side, 0));
-    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, n32, c->d_L);
+    if (xpair == 0xffffffffu) {
+        uint32_t nblk = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
+        uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
+        if (m < 1) m = 1;
+        nblk = (npairs + WAVE * m - 1) / (WAVE * m);
+        k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk);
+        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, xpair, c->d_L);
+    }
     HIPCHK(hipEventRecord(c->ev[6], st));
     k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1);
     HIPCHK(hipEventRecord(c->ev[7], st));
@@ -1332,6 +1462,11 @@ extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size
             return 0;
         case 3:
             if (out_bytes < 288) return MI355_BLS_ERR_ARG;
+            if (!c->agg_valid && c->sig_slots) {                     // bucket path: fold the bucket sums now
+                k_sig_fold<<<1, WAVE>>>(c->d_H, c->stride, (uint32_t)n, 64 / c->sig_c, c->sig_c, c->d_agg);
+                HIPCHK(hipGetLastError());
+                c->agg_valid = true;
+            }
             HIPCHK(hipMemcpy(out, c->d_agg, 288, hipMemcpyDeviceToHost));
             return 0;
         case 4:
@@ -1515,9 +1650,9 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_msm_convert<<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
-    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->hist);
+    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, 32, n, W, cb, m->hist);
     k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
-    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, n, W, cb, m->cursor, m->sorted);
+    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, 32, n, W, cb, m->cursor, m->sorted);
     uint32_t nbo = (total + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
     k_msm_order_hist<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist);
     k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
