@@ -239,6 +239,43 @@ BLS_HD fp fp_sqr_core(const fp& a) {
     return r;
 }
 
+
+// Montgomery "dot product" (a*b + c*d) * 2^-392 mod p with ONE reduction: 392 operand multiply-adds + 196 for the
+// reduction instead of 2 x 392 (lazy reduction; an Fp2 product is two of these and needs no Karatsuba
+// additions, subtractions or carries).  Column bound with limbs < 2^29 + 2^20: 28 * 2^58.01 + 14 * 2^56 < 2^63.
+BLS_HD fp fp_dot2_core(const fp& a, const fp& b, const fp& c, const fp& d) {
+    int64_t acc = 0;
+    int32_t m[FP_N];
+    fp r;
+#pragma unroll
+    for (int kk = 0; kk < FP_N; kk++) {
+#pragma unroll
+        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+#pragma unroll
+        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)c.l[i] * (int32_t)d.l[kk - i];
+#pragma unroll
+        for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
+        acc += (int64_t)m[kk] * (int32_t)k::P[0];
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)c.l[i] * (int32_t)d.l[kk - i];
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
+        acc >>= 28;
+    }
+    r.l[FP_N - 1] = (uint32_t)acc;
+    BLS_SET_VB(r, 2);
+    BLS_SET_LB(r, 0);
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // The multiplier body (~500 instructions) is shared by every caller so that hot loops fit the 64 KB
 // instruction cache.  Operands travel in VGPRs: 28 scalar parameters map to v0..v27 and the result
@@ -286,6 +323,18 @@ __host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
     }
 #endif
     return fp_sqr_core(a);
+}
+__host__ __device__ __noinline__ inline fp fp_dot2(const fp& a, const fp& b, const fp& c, const fp& d) {
+#if defined(BLS_TRACK_BOUNDS)
+    BLS_REQUIRE((uint64_t)BLS_VB(a) * BLS_VB(b) + (uint64_t)BLS_VB(c) * BLS_VB(d) <= 2048, "fp_dot2 value bounds");
+    BLS_REQUIRE(BLS_LB(a) <= 2 && BLS_LB(b) <= 2 && BLS_LB(c) <= 2 && BLS_LB(d) <= 2, "fp_dot2 limb-unit bounds");
+    const int64_t LIM = (1ll << 29) + (1ll << 20);
+    for (int i = 0; i < FP_N; i++) {
+        int64_t x = (int32_t)a.l[i], y = (int32_t)b.l[i], z = (int32_t)c.l[i], w = (int32_t)d.l[i];
+        BLS_REQUIRE(x > -LIM && x < LIM && y > -LIM && y < LIM && z > -LIM && z < LIM && w > -LIM && w < LIM, "fp_dot2 limb bound");
+    }
+#endif
+    return fp_dot2_core(a, b, c, d);
 }
 #endif
 
@@ -510,21 +559,69 @@ BLS_HD fp2 fp2_conj(const fp2& a) { return fp2{a.c0, fp_neg(a.c1)}; }
 BLS_HD fp2 fp2_mul3(const fp2& a) { return fp2_add(fp2_dbl(a), a); }
 BLS_HD fp2 fp2_reduce(const fp2& a) { return fp2{fp_reduce(a.c0), fp_reduce(a.c1)}; }
 
-// Karatsuba: 3 base multiplications; the operand sums skip the carry step (limbs < 2^30)
-BLS_HD fp2 fp2_mul(const fp2& a, const fp2& b) {
-    fp t0 = fp_mul(a.c0, b.c0);
-    fp t1 = fp_mul(a.c1, b.c1);
-    fp s = fp_mul(fp_add_nc(a.c0, a.c1), fp_add_nc(b.c0, b.c1));
-    // t0 - t1: non-negative limbs on both sides, no carry; s - t0 - t1: one carry for two subtractions
-    return fp2{fp_sub_pos(t0, t1), fp_carry(fp_sub_nc(fp_sub_pos(s, t0), t1))};
-}
 
-// complex squaring: 2 base multiplications
-BLS_HD fp2 fp2_sqr(const fp2& a) {
-    fp t = fp_mul(a.c0, a.c1);
-    fp c0 = fp_mul(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1));
-    return fp2{c0, fp_dbl(t)};
+#if defined(__HIP_DEVICE_COMPILE__)
+// Whole Fp2 operations as ONE out-of-line call each (results return in v0..v27 as a 32-wide vector; a 28-word
+// struct would go through memory).  fp2_mul_regs takes 56 words: the last 24 travel on the stack.
+typedef uint32_t bls_u32x32 __attribute__((ext_vector_type(32)));
+__device__ __forceinline__ bls_u32x32 fp2_pack(const fp& c0, const fp& c1) {
+    bls_u32x32 r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        r[i] = c0.l[i];
+        r[FP_N + i] = c1.l[i];
+    }
+    r[28] = 0; r[29] = 0; r[30] = 0; r[31] = 0;
+    return r;
 }
+__device__ __noinline__ bls_u32x32 fp2_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27,
+                                                uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11, uint32_t b12, uint32_t b13, uint32_t b14, uint32_t b15, uint32_t b16, uint32_t b17, uint32_t b18, uint32_t b19, uint32_t b20, uint32_t b21, uint32_t b22, uint32_t b23, uint32_t b24, uint32_t b25, uint32_t b26, uint32_t b27) {
+    fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, y0{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}}, y1{{b14, b15, b16, b17, b18, b19, b20, b21, b22, b23, b24, b25, b26, b27}}, nx1;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) nx1.l[i] = 0u - x1.l[i];
+    return fp2_pack(fp_dot2_core(x0, y0, nx1, y1), fp_dot2_core(x0, y1, x1, y0));
+}
+__device__ __noinline__ bls_u32x32 fp2_sqr_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27) {
+    fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, sm, df, d0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        sm.l[i] = x0.l[i] + x1.l[i];
+        df.l[i] = x0.l[i] - x1.l[i];
+        d0.l[i] = 2 * x0.l[i];
+    }
+    return fp2_pack(fp_mul_core(sm, df), fp_mul_core(d0, x1));
+}
+#endif
+
+// Fp2 product: c0 = a0 b0 - a1 b1 and c1 = a0 b1 + a1 b0 as two lazily reduced dot products (4 operand products,
+// 2 reductions: the multiply-add count of Karatsuba's 3 full products without its additions and carries).
+// Operands: at most 2 limb units each (limb-wise sums of two carried values are fine).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ fp2 fp2_unpack(const bls_u32x32& r) {
+    fp2 o;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        o.c0.l[i] = r[i];
+        o.c1.l[i] = r[FP_N + i];
+    }
+    return o;
+}
+__device__ __forceinline__ fp2 fp2_mul(const fp2& a, const fp2& b) {
+    return fp2_unpack(fp2_mul_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13],
+                                   b.c0.l[0], b.c0.l[1], b.c0.l[2], b.c0.l[3], b.c0.l[4], b.c0.l[5], b.c0.l[6], b.c0.l[7], b.c0.l[8], b.c0.l[9], b.c0.l[10], b.c0.l[11], b.c0.l[12], b.c0.l[13], b.c1.l[0], b.c1.l[1], b.c1.l[2], b.c1.l[3], b.c1.l[4], b.c1.l[5], b.c1.l[6], b.c1.l[7], b.c1.l[8], b.c1.l[9], b.c1.l[10], b.c1.l[11], b.c1.l[12], b.c1.l[13]));
+}
+__device__ __forceinline__ fp2 fp2_sqr(const fp2& a) {
+    return fp2_unpack(fp2_sqr_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13]));
+}
+#else
+BLS_HD fp2 fp2_mul(const fp2& a, const fp2& b) {
+    return fp2{fp_dot2(a.c0, b.c0, fp_neg(a.c1), b.c1), fp_dot2(a.c0, b.c1, a.c1, b.c0)};
+}
+// complex squaring: 2 base multiplications, operand sums without carries (inputs: carried values)
+BLS_HD fp2 fp2_sqr(const fp2& a) {
+    return fp2{fp_mul(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1)), fp_mul(fp_dbl_nc(a.c0), a.c1)};
+}
+#endif
 
 BLS_HD fp2 fp2_mul_fp(const fp2& a, const fp& b) { return fp2{fp_mul(a.c0, b), fp_mul(a.c1, b)}; }
 
