@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
             have = true;
         }
     }
+    f = fp12_reduce(f);
     for (int d = 32; d >= 1; d >>= 1) {
         fp12 o = shfl_down_struct(f, d);
         f = fp12_mul(f, o);

@@ -22,6 +22,7 @@ BLS_HD fp6 fp6_mul_by_v(const fp6& a) { return fp6{fp2_mul_xi(a.a2), a.a0, a.a1}
 // bounds never accumulate across the Karatsuba layers
 BLS_HD fp6 fp6_add_nc(const fp6& a, const fp6& b) { return fp6{fp2_add_nc(a.a0, b.a0), fp2_add_nc(a.a1, b.a1), fp2_add_nc(a.a2, b.a2)}; }
 BLS_HD fp6 fp6_sub_nc(const fp6& a, const fp6& b) { return fp6{fp2_sub_nc(a.a0, b.a0), fp2_sub_nc(a.a1, b.a1), fp2_sub_nc(a.a2, b.a2)}; }
+BLS_HD fp6 fp6_carry(const fp6& a) { return fp6{fp2_carry(a.a0), fp2_carry(a.a1), fp2_carry(a.a2)}; }
 BLS_HD fp6 fp6_reduce(const fp6& a) { return fp6{fp2_reduce(a.a0), fp2_reduce(a.a1), fp2_reduce(a.a2)}; }
 
 // 6 fp2 multiplications
@@ -100,8 +101,11 @@ BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     fp6 s = fp6_mul_by_01(fp6_add(f.c0, f.c1), l.l0, fp2_add(l.l1, l.l2));
     fp6 c1 = fp6_sub_nc(fp6_sub_nc(s, t0), t1);            // 2 + 2 + 1 limb units
     fp6 c0 = fp6_add_nc(t0, fp6_mul_by_v(t1));             // 2 + 1
-    return fp12{fp6_reduce(c0), fp6_reduce(c1)};
+    // Only carried, not reduced: every coefficient is a sum of at most 8 products (|v| < 16p), which is stable
+    // under repeated multiplication by reduced lines.  Reduce (fp12_reduce) before a general fp12_mul.
+    return fp12{fp6_carry(c0), fp6_carry(c1)};
 }
+BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
 
 BLS_HD fp12 fp12_from_line(const line_t& l) {
     return fp12{fp6{l.l0, l.l1, fp2_zero()}, fp6{fp2_zero(), l.l2, fp2_zero()}};

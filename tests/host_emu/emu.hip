@@ -46,7 +46,7 @@ void emu_pairing_product(const uint8_t* ps, const uint8_t* qs, uint32_t n, uint8
     for (int s = 0; s < N_LINES; s++) L[s] = fp12_one();
     for (uint32_t i = 0; i < n; i++)
         miller_lines(g1_jac_load(ps + 144 * i), g2_jac_load(qs + 288 * i), [&](int s, const line_t& l) { L[s] = fp12_mul_by_line(L[s], l); });
-    fp12 f = miller_combine([&](int s) { return L[s]; });
+    fp12 f = miller_combine([&](int s) { return fp12_reduce(L[s]); });      // as k_lineprod does before its product tree
     if (do_final_exp) f = final_exp(f);
     fp12_store_le(out, f);
 }

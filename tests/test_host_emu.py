@@ -116,6 +116,10 @@ def test_pairing_projective_inputs_and_product(emu):
     qs3 = qs + g2_aff_to_jac_bytes(q)
     emu.emu_pairing_product(ps3, qs3, 3, out, 1)
     assert fp12_from_bytes(out.raw) == o.F12_ONE
+    # longer per-step line products (the accumulator is only carried between lines, not reduced: the bound
+    # tracker of this build checks that this stays within the multiplier's preconditions)
+    emu.emu_pairing_product(ps3 * 3, qs3 * 3, 9, out, 1)
+    assert fp12_from_bytes(out.raw) == o.F12_ONE
 
 
 def _random_curve_point_g1(rng):
