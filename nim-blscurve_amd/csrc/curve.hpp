@@ -93,7 +93,7 @@ BLS_MID jac<F> jac_dbl(const jac<F>& p) {
     jac<F> r;
     r.x = f_red(f_sub_nc(Fq, f_dbl_nc(D)));
     F C8 = f_dbl_nc(f_carry(f_dbl_nc(f_dbl_nc(C))));
-    r.y = f_carry(f_sub_nc(f_mul(E, f_sub(D, r.x)), C8));     // y, z: carried only (|y| < 19p, |z| < 5p)
+    r.y = f_carry(f_sub_nc(f_mul(E, f_sub_nc(D, r.x)), C8));     // y, z: carried only (|y| < 19p, |z| < 5p)
     r.z = f_carry(f_dbl_nc(f_mul(p.y, p.z)));
     return r;
 }
@@ -115,7 +115,7 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     F V = f_mul(p.x, HH);
     jac<F> r;
     r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
-    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub(V, r.x)), f_mul(p.y, HHH)));
+    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub_nc(V, r.x)), f_mul(p.y, HHH)));
     r.z = f_mul(p.z, H);   // = 0 when P == -Q
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, jac_from_aff(q), r);
@@ -142,7 +142,7 @@ BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
     F V = f_mul(U1, HH);
     jac<F> r;
     r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
-    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub(V, r.x)), f_mul(S1, HHH)));
+    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub_nc(V, r.x)), f_mul(S1, HHH)));
     r.z = f_mul(f_mul(p.z, q.z), H);
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, q, r);

@@ -627,6 +627,7 @@ BLS_HD fp2 fp2_mul_fp(const fp2& a, const fp& b) { return fp2{fp_mul(a.c0, b), f
 
 // multiply by the sextic non-residue xi = 1+u
 BLS_HD fp2 fp2_mul_xi(const fp2& a) { return fp2{fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }
+BLS_HD fp2 fp2_mul_xi_nc(const fp2& a) { return fp2{fp_sub_nc(a.c0, a.c1), fp_add_nc(a.c0, a.c1)}; }
 
 BLS_HD fp fp2_norm(const fp2& a) { return fp_add(fp_sqr(a.c0), fp_sqr(a.c1)); }
 

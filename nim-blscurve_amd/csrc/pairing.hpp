@@ -45,7 +45,7 @@ BLS_MID line_t miller_dbl_step(g2_jac& t, const g1_pre& p) {
     fp2 Fq = fp2_sqr(E);
     fp2 zz = fp2_sqr(t.z);
     fp2 x3 = fp2_reduce(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
-    fp2 y3 = fp2_sub_nc(fp2_mul(E, fp2_sub(D, x3)), fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_dbl_nc(C)))));     // carried below
+    fp2 y3 = fp2_sub_nc(fp2_mul(E, fp2_sub_nc(D, x3)), fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_dbl_nc(C)))));     // carried below
     fp2 z3 = fp2_dbl(fp2_mul(t.y, t.z));
     // line * (Z3 * Z^2):  (E*X - 2B)  -  E*Z^2 * xp v  +  Z3*Z^2 * yp vw
     fp2 c0 = fp2_carry(fp2_sub_nc(fp2_mul(E, t.x), fp2_dbl_nc(B)));
@@ -73,7 +73,7 @@ BLS_MID line_t miller_add_step(g2_jac& t, const g2_jac& q, const g2_addpre& qp, 
     fp2 HHH = fp2_mul(H, HH);
     fp2 V = fp2_mul(U1, HH);
     fp2 x3 = fp2_reduce(fp2_sub_nc(fp2_sub_nc(fp2_sqr(rr), HHH), fp2_dbl_nc(V)));
-    fp2 y3 = fp2_sub_nc(fp2_mul(rr, fp2_sub(V, x3)), fp2_mul(S1, HHH));                                      // carried below
+    fp2 y3 = fp2_sub_nc(fp2_mul(rr, fp2_sub_nc(V, x3)), fp2_mul(S1, HHH));                                      // carried below
     fp2 z3 = fp2_mul(fp2_mul(t.z, q.z), H);
     // slope = rr / Z3.  line * (Z3 * Zq^3): (rr*Xq*Zq - Yq*Z3) - rr*Zq^3 * xp v + Z3*Zq^3 * yp vw
     fp2 c0 = fp2_sub(fp2_mul(rr, fp2_mul(q.x, q.z)), fp2_mul(q.y, z3));

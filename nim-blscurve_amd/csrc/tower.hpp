@@ -26,33 +26,19 @@ BLS_HD fp6 fp6_carry(const fp6& a) { return fp6{fp2_carry(a.a0), fp2_carry(a.a1)
 BLS_HD fp6 fp6_reduce(const fp6& a) { return fp6{fp2_reduce(a.a0), fp2_reduce(a.a1), fp2_reduce(a.a2)}; }
 
 // 6 fp2 multiplications
+// Karatsuba, 6 fp2 multiplications.  Operands carried (1 limb unit): their pairwise sums feed the multiplier
+// un-carried; each result coefficient takes one carry step.
 BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
     fp2 t0 = fp2_mul(a.a0, b.a0);
     fp2 t1 = fp2_mul(a.a1, b.a1);
     fp2 t2 = fp2_mul(a.a2, b.a2);
-    fp2 c0 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.a1, a.a2), fp2_add(b.a1, b.a2)), t1), t2);
-    c0 = fp2_add(t0, fp2_mul_xi(c0));
-    fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.a0, a.a1), fp2_add(b.a0, b.a1)), t0), t1);
-    c1 = fp2_add(c1, fp2_mul_xi(t2));
-    fp2 c2 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a.a0, a.a2), fp2_add(b.a0, b.a2)), t0), t2);
-    c2 = fp2_add(c2, t1);
+    fp2 c0 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add_nc(a.a1, a.a2), fp2_add_nc(b.a1, b.a2)), t1), t2);       // 3 units
+    c0 = fp2_carry(fp2_add_nc(t0, fp2_mul_xi_nc(c0)));                                                     // 1 + 6
+    fp2 c1 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add_nc(a.a0, a.a1), fp2_add_nc(b.a0, b.a1)), t0), t1);
+    c1 = fp2_carry(fp2_add_nc(c1, fp2_mul_xi_nc(t2)));                                                     // 3 + 2
+    fp2 c2 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add_nc(a.a0, a.a2), fp2_add_nc(b.a0, b.a2)), t0), t2);
+    c2 = fp2_carry(fp2_add_nc(c2, t1));
     return fp6{c0, c1, c2};
-}
-
-// a * (l0 + l1 v): 5 fp2 multiplications
-BLS_MID fp6 fp6_mul_by_01(const fp6& a, const fp2& l0, const fp2& l1) {
-    fp2 t0 = fp2_mul(a.a0, l0);
-    fp2 t1 = fp2_mul(a.a1, l1);
-    // results keep at most 2 limb units (c1 is carried): the caller sums them limb-wise and reduces once
-    fp2 c1 = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add(a.a0, a.a1), fp2_add(l0, l1)), t0), t1));
-    fp2 c0 = fp2_add_nc(t0, fp2_mul_xi(fp2_mul(a.a2, l1)));
-    fp2 c2 = fp2_add_nc(t1, fp2_mul(a.a2, l0));
-    return fp6{c0, c1, c2};
-}
-
-// a * (l1 v): 3 fp2 multiplications
-BLS_HD fp6 fp6_mul_by_1(const fp6& a, const fp2& l1) {
-    return fp6{fp2_mul_xi(fp2_mul(a.a2, l1)), fp2_mul(a.a0, l1), fp2_mul(a.a1, l1)};
 }
 
 BLS_HDN fp6 fp6_inv(const fp6& a) {
@@ -76,8 +62,8 @@ BLS_HD bool fp12_is_one(const fp12& a) {
 BLS_HDN fp12 fp12_mul(const fp12& a, const fp12& b) {
     fp6 t0 = fp6_mul(a.c0, b.c0);
     fp6 t1 = fp6_mul(a.c1, b.c1);
-    fp6 c1 = fp6_sub(fp6_sub(fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1)), t0), t1);
-    fp6 c0 = fp6_add(t0, fp6_mul_by_v(t1));
+    fp6 c1 = fp6_sub_nc(fp6_sub_nc(fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1)), t0), t1);
+    fp6 c0 = fp6_add_nc(t0, fp6_mul_by_v(t1));
     return fp12{fp6_reduce(c0), fp6_reduce(c1)};
 }
 
@@ -85,8 +71,8 @@ BLS_HDN fp12 fp12_mul(const fp12& a, const fp12& b) {
 BLS_HDN fp12 fp12_sqr(const fp12& a) {
     fp6 t = fp6_mul(a.c0, a.c1);
     fp6 s = fp6_mul(fp6_add(a.c0, a.c1), fp6_add(a.c0, fp6_mul_by_v(a.c1)));
-    fp6 c0 = fp6_sub(fp6_sub(s, t), fp6_mul_by_v(t));
-    return fp12{fp6_reduce(c0), fp6_reduce(fp6_dbl(t))};
+    fp6 c0 = fp6_sub_nc(fp6_sub_nc(s, t), fp6_mul_by_v(t));
+    return fp12{fp6_reduce(c0), fp6_reduce(fp6_add_nc(t, t))};
 }
 
 // Miller-loop line  l = l0 + l1*v + l2*v*w  (coefficients at tower slots c0.a0, c0.a1, c1.a1)
@@ -94,16 +80,33 @@ struct line_t {
     fp2 l0, l1, l2;
 };
 
-// f * line: 13 fp2 multiplications
+// f * line: 13 fp2 multiplications (Karatsuba over w: t0 = f.c0 (l0 + l1 v), t1 = f.c1 (l2 v),
+// s = (f.c0 + f.c1)(l0 + (l1 + l2) v); each sparse Fp6 product is 5 resp. 3 Fp2 products).
+// The sums are limb-wise: multiplier operands may hold 2 limb units, everything else up to 7, so only the two
+// three-term operand sums and the 12 result coefficients take a carry step (18 instead of 40 per line).
+// Inputs: f and the line coefficients carried (at most 1 limb unit).  The result is carried, NOT reduced:
+// every coefficient is a sum of at most 8 products (|v| < 16p), which is stable under repeated multiplication
+// by reduced lines.  Reduce (fp12_reduce) before a general fp12_mul.
 BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
-    fp6 t0 = fp6_mul_by_01(f.c0, l.l0, l.l1);
-    fp6 t1 = fp6_mul_by_1(f.c1, l.l2);
-    fp6 s = fp6_mul_by_01(fp6_add(f.c0, f.c1), l.l0, fp2_add(l.l1, l.l2));
-    fp6 c1 = fp6_sub_nc(fp6_sub_nc(s, t0), t1);            // 2 + 2 + 1 limb units
-    fp6 c0 = fp6_add_nc(t0, fp6_mul_by_v(t1));             // 2 + 1
-    // Only carried, not reduced: every coefficient is a sum of at most 8 products (|v| < 16p), which is stable
-    // under repeated multiplication by reduced lines.  Reduce (fp12_reduce) before a general fp12_mul.
-    return fp12{fp6_carry(c0), fp6_carry(c1)};
+    const fp6 &a = f.c0, &b = f.c1;
+    fp2 a0l0 = fp2_mul(a.a0, l.l0), a1l1 = fp2_mul(a.a1, l.l1);
+    fp2 t0c1 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add_nc(a.a0, a.a1), fp2_add_nc(l.l0, l.l1)), a0l0), a1l1);      // 3 units
+    fp2 t0c0 = fp2_add_nc(a0l0, fp2_mul_xi_nc(fp2_mul(a.a2, l.l1)));                                            // 3
+    fp2 t0c2 = fp2_add_nc(a1l1, fp2_mul(a.a2, l.l0));                                                           // 2
+    fp2 t1a0 = fp2_mul_xi(fp2_mul(b.a2, l.l2)), t1a1 = fp2_mul(b.a0, l.l2), t1a2 = fp2_mul(b.a1, l.l2);          // 1 each
+    fp2 s0 = fp2_add_nc(a.a0, b.a0), s1 = fp2_add_nc(a.a1, b.a1), s2 = fp2_add_nc(a.a2, b.a2), m1 = fp2_add_nc(l.l1, l.l2);
+    fp2 s0l0 = fp2_mul(s0, l.l0), s1m1 = fp2_mul(s1, m1);
+    fp2 sc1 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_carry(fp2_add_nc(s0, s1)), fp2_carry(fp2_add_nc(l.l0, m1))), s0l0), s1m1);   // 3
+    fp2 sc0 = fp2_add_nc(s0l0, fp2_mul_xi_nc(fp2_mul(s2, m1)));                                                 // 3
+    fp2 sc2 = fp2_add_nc(s1m1, fp2_mul(s2, l.l0));                                                              // 2
+    fp12 r;
+    r.c1.a0 = fp2_carry(fp2_sub_nc(fp2_sub_nc(sc0, t0c0), t1a0));             // c1 = s - t0 - t1: 3 + 3 + 1
+    r.c1.a1 = fp2_carry(fp2_sub_nc(fp2_sub_nc(sc1, t0c1), t1a1));
+    r.c1.a2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(sc2, t0c2), t1a2));
+    r.c0.a0 = fp2_carry(fp2_add_nc(t0c0, fp2_mul_xi_nc(t1a2)));               // c0 = t0 + v t1
+    r.c0.a1 = fp2_carry(fp2_add_nc(t0c1, t1a0));
+    r.c0.a2 = fp2_carry(fp2_add_nc(t0c2, t1a1));
+    return r;
 }
 BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
 
