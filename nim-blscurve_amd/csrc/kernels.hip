@@ -240,6 +240,35 @@ __global__ void __launch_bounds__(WAVE) k_hash(const uint8_t* __restrict__ sets,
     soa_st_g2(H, stride, i, h);
 }
 
+// Batch form of hash-to-G2 in two kernels.  k_hash_map: TWO lanes per message, lane j maps u_j (SSWU + 3-isogeny:
+// Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
+// each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
+// (G2 arithmetic: needs the full register file).
+__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
+    if (i >= n) return;
+    uint8_t msg[32];
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t w = mw[j];
+        msg[4 * j] = (uint8_t)w;
+        msg[4 * j + 1] = (uint8_t)(w >> 8);
+        msg[4 * j + 2] = (uint8_t)(w >> 16);
+        msg[4 * j + 3] = (uint8_t)(w >> 24);
+    }
+    fp2 u0, u1;
+    hash_to_field_fp2x2(u0, u1, msg, 32, dst.b, dst.len);
+    fp2 u = fp2_select((t & 1) != 0, u1, u0);
+    soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
+}
+__global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
+    soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
+}
+
 // arbitrary-length message (fastAggregateVerify / coreVerify shape), one lane
 __global__ void k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1121,6 +1150,8 @@ struct mi355_bls_ctx {
     uint8_t* d_rnd = nullptr;
     uint64_t* d_r = nullptr;
     uint4* d_H = nullptr;
+    uint4* d_M = nullptr;            // the two mapped points per message before cofactor clearing (2 x cap Jacobian slots)
+    size_t mstride = 0;
     uint4* d_P = nullptr;
     uint4* d_lines = nullptr;
     uint32_t* d_spart = nullptr;
@@ -1166,7 +1197,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -1214,6 +1245,8 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_rnd, 32);
     ALLOC(c->d_r, c->stride * 8);
     ALLOC(c->d_H, c->stride * 6 * 64);
+    c->mstride = ((2 * max_sets + 63) / 64) * 64;
+    ALLOC(c->d_M, c->mstride * 6 * 64);
     ALLOC(c->d_P, c->stride * 3 * 64);
     ALLOC(c->d_lines, c->stride * 6 * 64 * (size_t)N_LINES);
     ALLOC(c->d_spart, (nwaves + 16) * G2W * 4);
@@ -1280,7 +1313,8 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, serial, c->d_r);
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_hash<<<nb, WAVE, 0, st>>>(d_sets, n32, c->dst, c->d_H, c->stride);
+    k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->d_M, c->mstride);
+    k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[3], st));
