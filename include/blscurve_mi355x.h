@@ -168,6 +168,9 @@ int mi355_bls_fetch_stage(mi355_bls_ctx* ctx, int what, void* out, size_t out_by
 /* Kernel timing of the last batch call, ms per stage measured with HIP events on the call's stream:
  * out[0..7] = blinding, hash_to_g2, pk_mul, sig_mul+sum, miller_lines, line_products, final, total. */
 int mi355_bls_last_timings(mi355_bls_ctx* ctx, float out[8]);
+/* Per-kernel split of the two-kernel stages of the last batch call (ms): k_hash_map, k_hash_clear (hash_to_g2),
+ * k_lineprod, k_lineprod2 (line_products). */
+int mi355_bls_last_kernel_timings(mi355_bls_ctx* ctx, float out[4]);
 
 #ifdef __cplusplus
 }

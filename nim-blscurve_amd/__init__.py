@@ -76,6 +76,7 @@ def lib():
         L.mi355_bls_aggregate_verify.argtypes = [vp, cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.mi355_bls_last_kernel_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib
 
@@ -149,6 +150,12 @@ class BatchedBLSVerifierCache:
         _check(lib().mi355_bls_last_timings(self._h, t))
         names = ["blinding", "hash_to_g2", "pk_mul", "sig_mul_sum", "miller_lines", "line_products", "final", "total"]
         return dict(zip(names, list(t)))
+
+    def kernel_timings(self):
+        """ms of the kernels inside the two-kernel stages of the last batch call."""
+        t = (ctypes.c_float * 4)()
+        _check(lib().mi355_bls_last_kernel_timings(self._h, t))
+        return dict(zip(["k_hash_map", "k_hash_clear", "k_lineprod", "k_lineprod2"], list(t)))
 
     # -- device-resident entry points --
     def verify_device(self, d_ptr, n, secureRandomBytes, stream=0):

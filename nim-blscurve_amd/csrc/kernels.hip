@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
         fp12 o = ld_fp12_int(part + ((size_t)s * nblk + j) * F12W);
         f = fp12_mul(f, o);
     }
-    for (int d = 32; d >= 1; d >>= 1) {
+    int top = 32;                                   // lanes >= nblk hold 1: skip the tree levels that only fold ones
+    while (top >= 1 && (uint32_t)top >= nblk) top >>= 1;
+    for (int d = top; d >= 1; d >>= 1) {
         fp12 o = shfl_down_struct(f, d);
         f = fp12_mul(f, o);
     }
@@ -1177,6 +1179,8 @@ struct mi355_bls_ctx {
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
     hipEvent_t ev_side = nullptr;
+    hipEvent_t ev_hm = nullptr, ev_lp = nullptr;   // inside the hash stage (after k_hash_map) and the line-product stage (after k_lineprod)
+    float ktimes[4] = {};         // k_hash_map, k_hash_clear, k_lineprod, k_lineprod2 of the last batch call
     hipStream_t side = nullptr;   // one-wave side work that runs beside a main-stream kernel
     uint32_t slots = 1024;        // wave slots at one wave per SIMD: 4 x CUs
     size_t last_n = 0;
@@ -1203,6 +1207,8 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->ev_hm) (void)hipEventDestroy(c->ev_hm);
+    if (c->ev_lp) (void)hipEventDestroy(c->ev_lp);
     if (c->ev_deser0) (void)hipEventDestroy(c->ev_deser0);
     if (c->ev_deser1) (void)hipEventDestroy(c->ev_deser1);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -1268,6 +1274,8 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_hm));
+    HIPCHK(hipEventCreate(&c->ev_lp));
     HIPCHK(hipEventCreate(&c->ev_deser0));
     HIPCHK(hipEventCreate(&c->ev_deser1));
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -1314,6 +1322,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, serial, c->d_r);
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->d_M, c->mstride);
+    HIPCHK(hipEventRecord(c->ev_hm, st));
     k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
@@ -1378,6 +1387,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         if (m0 < 1) m0 = 1;
         nblk0 = (n32 + WAVE * m0 - 1) / (WAVE * m0);
         k_lineprod<<<dim3(N_LINES, nblk0), WAVE, 0, st>>>(c->d_lines, n32, c->stride, m0, c->d_lpart, nblk0);
+        HIPCHK(hipEventRecord(c->ev_lp, st));
         if (use_side) HIPCHK(hipStreamWaitEvent(st, c->ev_side, 0));
         k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk0, c->d_lines, c->stride, xpair, c->d_L);
     }
@@ -1387,6 +1397,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         if (m < 1) m = 1;
         nblk = (npairs + WAVE * m - 1) / (WAVE * m);
         k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk);
+        HIPCHK(hipEventRecord(c->ev_lp, st));
         k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, xpair, c->d_L);
     }
     HIPCHK(hipEventRecord(c->ev[6], st));
@@ -1400,6 +1411,13 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
 
 static int collect_timings(mi355_bls_ctx* c, int last_ev) {
     for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    for (int i = 0; i < 4; i++) c->ktimes[i] = 0;
+    if (last_ev == 7) {                           // batch path: per-kernel split of the two-kernel stages
+        HIPCHK(hipEventElapsedTime(&c->ktimes[0], c->ev[1], c->ev_hm));
+        HIPCHK(hipEventElapsedTime(&c->ktimes[1], c->ev_hm, c->ev[2]));
+        HIPCHK(hipEventElapsedTime(&c->ktimes[2], c->ev[5], c->ev_lp));
+        HIPCHK(hipEventElapsedTime(&c->ktimes[3], c->ev_lp, c->ev[6]));
+    }
     for (int i = 0; i < last_ev; i++) HIPCHK(hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]));
     HIPCHK(hipEventElapsedTime(&c->timings[7], c->ev[0], c->ev[last_ev]));
     return 0;
@@ -1514,6 +1532,12 @@ extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size
             return 0;
     }
     return MI355_BLS_ERR_ARG;
+}
+
+extern "C" int mi355_bls_last_kernel_timings(mi355_bls_ctx* c, float out[4]) {
+    if (!c || !out) return MI355_BLS_ERR_ARG;
+    for (int i = 0; i < 4; i++) out[i] = c->ktimes[i];
+    return 0;
 }
 
 extern "C" int mi355_bls_last_timings(mi355_bls_ctx* c, float out[8]) {
