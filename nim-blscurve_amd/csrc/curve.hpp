@@ -122,9 +122,11 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     return r;
 }
 
-// Jacobian + Jacobian, complete.
+// Jacobian + Jacobian, complete.  Out of line (jac_add_impl takes references, i.e. memory operands); callers go
+// through the by-value wrapper jac_add below so that only its private copies have their address taken and
+// the caller's own (often loop-carried) points stay in registers.
 template <class F>
-BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
+BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) {
     bool p_inf = jac_is_inf(p);
     bool q_inf = jac_is_inf(q);
     F Z1Z1 = f_sqr(p.z);
@@ -148,6 +150,9 @@ BLS_HDN jac<F> jac_add(const jac<F>& p, const jac<F>& q) {
     r = jac_select(p_inf, q, r);
     return r;
 }
+
+template <class F>
+BLS_HD jac<F> jac_add(jac<F> p, jac<F> q) { return jac_add_impl(p, q); }
 
 // [k]P for a 64-bit scalar, affine base; left-to-right double-and-add.  Not constant time: the
 // blinding scalars are public (blst_min_pubkey_sig_core.nim:531-541 rationale).

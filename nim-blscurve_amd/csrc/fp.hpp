@@ -562,7 +562,7 @@ BLS_HD fp2 fp2_reduce(const fp2& a) { return fp2{fp_reduce(a.c0), fp_reduce(a.c1
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Whole Fp2 operations as ONE out-of-line call each (results return in v0..v27 as a 32-wide vector; a 28-word
-// struct would go through memory).  fp2_mul_regs takes 56 words: the last 24 travel on the stack.
+// struct would go through memory).
 typedef uint32_t bls_u32x32 __attribute__((ext_vector_type(32)));
 __device__ __forceinline__ bls_u32x32 fp2_pack(const fp& c0, const fp& c1) {
     bls_u32x32 r;
@@ -574,11 +574,26 @@ __device__ __forceinline__ bls_u32x32 fp2_pack(const fp& c0, const fp& c1) {
     r[28] = 0; r[29] = 0; r[30] = 0; r[31] = 0;
     return r;
 }
-__device__ __noinline__ bls_u32x32 fp2_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27,
-                                                uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11, uint32_t b12, uint32_t b13, uint32_t b14, uint32_t b15, uint32_t b16, uint32_t b17, uint32_t b18, uint32_t b19, uint32_t b20, uint32_t b21, uint32_t b22, uint32_t b23, uint32_t b24, uint32_t b25, uint32_t b26, uint32_t b27) {
-    fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, y0{{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}}, y1{{b14, b15, b16, b17, b18, b19, b20, b21, b22, b23, b24, b25, b26, b27}}, nx1;
+// Second operand of fp2_mul_regs: 28 words per lane handed over through LDS (7 x 16 bytes, [group][lane] so a
+// wave's accesses are conflict-free).  Registers carry only 32 argument words; the rest would travel on the
+// stack, i.e. through scratch memory, which at 1024 waves x 13 products per line was ~6 GB of HBM writes per
+// k_lineprod launch.  Every kernel of this library runs one wave per workgroup, so the slot is wave-private.
+static __shared__ uint4 bls_xchg[7 * 64];
+__device__ __noinline__ bls_u32x32 fp2_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27) {
+    fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, y0, y1, nx1;
+    uint32_t yw[28];
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int i = 0; i < FP_N; i++) nx1.l[i] = 0u - x1.l[i];
+    for (int q = 0; q < 7; q++) {
+        uint4 v = bls_xchg[q * 64 + lane];
+        yw[4 * q] = v.x; yw[4 * q + 1] = v.y; yw[4 * q + 2] = v.z; yw[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        y0.l[i] = yw[i];
+        y1.l[i] = yw[FP_N + i];
+        nx1.l[i] = 0u - x1.l[i];
+    }
     return fp2_pack(fp_dot2_core(x0, y0, nx1, y1), fp_dot2_core(x0, y1, x1, y0));
 }
 __device__ __noinline__ bls_u32x32 fp2_sqr_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27) {
@@ -607,8 +622,16 @@ __device__ __forceinline__ fp2 fp2_unpack(const bls_u32x32& r) {
     return o;
 }
 __device__ __forceinline__ fp2 fp2_mul(const fp2& a, const fp2& b) {
-    return fp2_unpack(fp2_mul_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13],
-                                   b.c0.l[0], b.c0.l[1], b.c0.l[2], b.c0.l[3], b.c0.l[4], b.c0.l[5], b.c0.l[6], b.c0.l[7], b.c0.l[8], b.c0.l[9], b.c0.l[10], b.c0.l[11], b.c0.l[12], b.c0.l[13], b.c1.l[0], b.c1.l[1], b.c1.l[2], b.c1.l[3], b.c1.l[4], b.c1.l[5], b.c1.l[6], b.c1.l[7], b.c1.l[8], b.c1.l[9], b.c1.l[10], b.c1.l[11], b.c1.l[12], b.c1.l[13]));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t yw[28];
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        yw[i] = b.c0.l[i];
+        yw[FP_N + i] = b.c1.l[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 7; q++) bls_xchg[q * 64 + lane] = make_uint4(yw[4 * q], yw[4 * q + 1], yw[4 * q + 2], yw[4 * q + 3]);
+    return fp2_unpack(fp2_mul_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13]));
 }
 __device__ __forceinline__ fp2 fp2_sqr(const fp2& a) {
     return fp2_unpack(fp2_sqr_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13]));

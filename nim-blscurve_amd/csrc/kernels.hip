@@ -358,14 +358,23 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
     uint32_t s = blockIdx.x, b = blockIdx.y;
     const uint4* base = lines + (size_t)s * 24 * stride;
     size_t first = (size_t)b * WAVE * m;
+    // Straight-line accumulation (no "have a value yet" flag, no per-lane conditional update: those made the
+    // compiler keep f in scratch memory across iterations).  Lanes past the end multiply by the line 1; a round
+    // with no valid lane at all ends the loop (wave-uniform test).
+    auto ld_line = [&](size_t j0) {
+        size_t i = j0 + threadIdx.x;
+        bool v = i < npairs;
+        size_t ia = v ? i : j0;
+        line_t l{soa_ld2(base, stride, 0, ia), soa_ld2(base, stride, 2, ia), soa_ld2(base, stride, 4, ia)};
+        return line_t{fp2_select(v, l.l0, fp2_one()), fp2_select(v, l.l1, fp2_zero()), fp2_select(v, l.l2, fp2_zero())};
+    };
     fp12 f = fp12_one();
-    bool have = false;
-    for (uint32_t j = 0; j < m; j++) {
-        size_t i = first + (size_t)j * WAVE + threadIdx.x;
-        if (i < npairs) {
-            line_t l{soa_ld2(base, stride, 0, i), soa_ld2(base, stride, 2, i), soa_ld2(base, stride, 4, i)};
-            f = have ? fp12_mul_by_line(f, l) : fp12_from_line(l);
-            have = true;
+    if (first < npairs) {
+        f = fp12_from_line(ld_line(first));
+        for (uint32_t j = 1; j < m; j++) {
+            size_t j0 = first + (size_t)j * WAVE;
+            if (j0 >= npairs) break;
+            f = fp12_mul_by_line(f, ld_line(j0));
         }
     }
     f = fp12_reduce(f);

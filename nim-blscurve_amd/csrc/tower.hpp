@@ -28,7 +28,7 @@ BLS_HD fp6 fp6_reduce(const fp6& a) { return fp6{fp2_reduce(a.a0), fp2_reduce(a.
 // 6 fp2 multiplications
 // Karatsuba, 6 fp2 multiplications.  Operands carried (1 limb unit): their pairwise sums feed the multiplier
 // un-carried; each result coefficient takes one carry step.
-BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
+BLS_HDN fp6 fp6_mul_impl(const fp6& a, const fp6& b) {
     fp2 t0 = fp2_mul(a.a0, b.a0);
     fp2 t1 = fp2_mul(a.a1, b.a1);
     fp2 t2 = fp2_mul(a.a2, b.a2);
@@ -40,6 +40,9 @@ BLS_HDN fp6 fp6_mul(const fp6& a, const fp6& b) {
     c2 = fp2_carry(fp2_add_nc(c2, t1));
     return fp6{c0, c1, c2};
 }
+
+// by-value wrappers: see jac_add (curve.hpp)
+BLS_HD fp6 fp6_mul(fp6 a, fp6 b) { return fp6_mul_impl(a, b); }
 
 BLS_HDN fp6 fp6_inv(const fp6& a) {
     fp2 c0 = fp2_sub(fp2_sqr(a.a0), fp2_mul_xi(fp2_mul(a.a1, a.a2)));
@@ -59,7 +62,7 @@ BLS_HD bool fp12_is_one(const fp12& a) {
 }
 
 // 3 fp6 multiplications (54 fp mul)
-BLS_HDN fp12 fp12_mul(const fp12& a, const fp12& b) {
+BLS_HDN fp12 fp12_mul_impl(const fp12& a, const fp12& b) {
     fp6 t0 = fp6_mul(a.c0, b.c0);
     fp6 t1 = fp6_mul(a.c1, b.c1);
     fp6 c1 = fp6_sub_nc(fp6_sub_nc(fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1)), t0), t1);
@@ -68,12 +71,16 @@ BLS_HDN fp12 fp12_mul(const fp12& a, const fp12& b) {
 }
 
 // complex squaring: 2 fp6 multiplications
-BLS_HDN fp12 fp12_sqr(const fp12& a) {
+BLS_HD fp12 fp12_mul(fp12 a, fp12 b) { return fp12_mul_impl(a, b); }
+
+BLS_HDN fp12 fp12_sqr_impl(const fp12& a) {
     fp6 t = fp6_mul(a.c0, a.c1);
     fp6 s = fp6_mul(fp6_add(a.c0, a.c1), fp6_add(a.c0, fp6_mul_by_v(a.c1)));
     fp6 c0 = fp6_sub_nc(fp6_sub_nc(s, t), fp6_mul_by_v(t));
     return fp12{fp6_reduce(c0), fp6_reduce(fp6_add_nc(t, t))};
 }
+
+BLS_HD fp12 fp12_sqr(fp12 a) { return fp12_sqr_impl(a); }
 
 // Miller-loop line  l = l0 + l1*v + l2*v*w  (coefficients at tower slots c0.a0, c0.a1, c1.a1)
 struct line_t {
