@@ -1287,7 +1287,6 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     HIPCHK(hipEventCreate(&c->ev_lp));
     HIPCHK(hipEventCreate(&c->ev_deser0));
     HIPCHK(hipEventCreate(&c->ev_deser1));
-    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->slots = 4u * (uint32_t)prop.multiProcessorCount;
@@ -1381,6 +1380,9 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         if (use_side) {
             k_lines<<<nb, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32, c->stride, c->d_lines);
             HIPCHK(hipEventRecord(c->ev[5], st));
+            // created on first use: a stream takes a share of a hardware queue, and callers that keep several
+            // contexts in flight want those for their own streams
+            if (!c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
             HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
             k_lines<<<1, WAVE, 0, c->side>>>(c->d_P, c->d_H, n32, 1, c->stride, c->d_lines);
             HIPCHK(hipEventRecord(c->ev_side, c->side));
