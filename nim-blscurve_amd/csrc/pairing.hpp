@@ -10,7 +10,8 @@
 //
 // Twist convention: E2: y^2 = x^3 + 4(1+u) (M-type), untwist (x,y) -> (x/w^2, y/w^3), w^6 = xi.
 // A line through T with slope lam evaluated at P=(xp,yp), times w^3 (killed by the final exp):
-//   (lam*xt - yt)  -  lam*xp * v  +  yp * v*w          -> tower slots c0.a0, c0.a1, c1.a1.
+//   (lam*xt - yt)  -  lam*xp * v  +  yp * v*w          -> tower slots c0.a0, c0.a1, c1.a1
+// (any non-zero factor from Fp2 may be applied to a line: the final exponentiation removes it).
 #pragma once
 #include "curve.hpp"
 #include "tower.hpp"
@@ -19,86 +20,91 @@ namespace bls {
 
 constexpr int N_LINES = 68;
 
-// P-side factors: for Jacobian P=(X,Y,Z), lines are scaled by Z^3: xp*Z^3 = X*Z, yp*Z^3 = Y.
+// P-side factors: for Jacobian P=(X,Y,Z), xp = X/Z^2 and yp = Y/Z^3; every line is scaled by Z^3 (an Fp
+// factor, killed by the final exponentiation): constant term * Z^3, xp term * X Z, yp term * Y.
 struct g1_pre {
-    fp z3, xz, y;
+    fp z3, xz, nxz3, y;      // Z^3, X Z, -3 X Z, Y
 };
 
 BLS_HD g1_pre g1_precompute(const g1_jac& p) {
     fp z2 = fp_sqr(p.z);
-    return g1_pre{fp_mul(z2, p.z), fp_mul(p.x, p.z), p.y};
-}
-
-BLS_HD line_t line_scale(const fp2& c0, const fp2& c1, const fp2& c2, const g1_pre& p) {
-    return line_t{fp2_mul_fp(c0, p.z3), fp2_mul_fp(c1, p.xz), fp2_mul_fp(c2, p.y)};
+    fp xz = fp_mul(p.x, p.z);
+    return g1_pre{fp_mul(z2, p.z), xz, fp_neg(fp_carry(fp_add_nc(fp_dbl_nc(xz), xz))), p.y};
 }
 
 BLS_HD line_t line_one() { return line_t{fp2_one(), fp2_zero(), fp2_zero()}; }
 
-// T <- 2T, returns tangent line at T evaluated at P.
-BLS_MID line_t miller_dbl_step(g2_jac& t, const g1_pre& p) {
-    fp2 A = fp2_sqr(t.x);
-    fp2 B = fp2_sqr(t.y);
-    fp2 C = fp2_sqr(B);
-    fp2 D = fp2_carry(fp2_dbl_nc(fp2_sub_nc(fp2_sub_nc(fp2_sqr(fp2_add(t.x, B)), A), C)));
-    fp2 E = fp2_carry(fp2_add_nc(fp2_dbl_nc(A), A));
-    fp2 Fq = fp2_sqr(E);
-    fp2 zz = fp2_sqr(t.z);
-    fp2 x3 = fp2_reduce(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
-    fp2 y3 = fp2_sub_nc(fp2_mul(E, fp2_sub_nc(D, x3)), fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_dbl_nc(C)))));     // carried below
-    fp2 z3 = fp2_dbl(fp2_mul(t.y, t.z));
-    // line * (Z3 * Z^2):  (E*X - 2B)  -  E*Z^2 * xp v  +  Z3*Z^2 * yp vw
-    fp2 c0 = fp2_carry(fp2_sub_nc(fp2_mul(E, t.x), fp2_dbl_nc(B)));
-    fp2 c1 = fp2_neg(fp2_mul(E, zz));
-    fp2 c2 = fp2_mul(z3, zz);
-    t = g2_jac{x3, fp2_carry(y3), z3};
-    return line_scale(c0, c1, c2, p);
+// The point T walking through the multiples of Q is kept in HOMOGENEOUS projective coordinates (x = X/Z,
+// y = Y/Z): for y^2 = x^3 + b' the doubling together with its tangent line takes 3 multiplications and 6
+// squarings in Fp2 (Costello, Lange, Naehrig, "Faster pairing computations on curves with high-degree twists",
+// PKC 2010, a = 0 case) against 5 + 6 in Jacobian coordinates.  Lines are defined up to factors in Fp2 (a proper
+// subfield of Fp12: such factors vanish in the final exponentiation), which is what lets the formulas drop
+// every denominator.
+using g2_proj = g2_jac;      // same three Fp2 coordinates, homogeneous meaning
+
+// Jacobian (X, Y, Z) -> homogeneous (X Z : Y : Z^3)
+BLS_HD g2_proj g2_to_proj(const g2_jac& q) {
+    fp2 z2 = fp2_sqr(q.z);
+    return g2_proj{fp2_mul(q.x, q.z), q.y, fp2_mul(z2, q.z)};
 }
 
-// Q-side factors for the 5 addition steps (Q Jacobian)
-struct g2_addpre {
-    fp2 z2, z3;     // Zq^2, Zq^3
-};
+// T <- 2T, returns the tangent line at T evaluated at P, times 2 Y Z^2 (an Fp2 factor):
+//   (Y^2 - 3b' Z^2)  -  3 X^2 * xp v  +  2 Y Z * yp vw          with b' = 4 xi
+//   X3 = 2 X Y (B - 3E), Y3 = (B + 3E)^2 - 12 E^2, Z3 = 4 B H;  B = Y^2, C = Z^2, E = 3 b' C, H = 2 Y Z
+BLS_MID line_t miller_dbl_step(g2_proj& t, const g1_pre& p) {
+    fp2 B = fp2_sqr(t.y);
+    fp2 C = fp2_sqr(t.z);
+    fp2 X2 = fp2_sqr(t.x);
+    fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));                       // 4 xi C   (2 -> 4 units, carry, 2)
+    fp2 E = fp2_reduce(fp2_add_nc(fp2_dbl_nc(C4), C4));                                 // 12 xi C = 3 b' C   (6 units)
+    fp2 F = fp2_add_nc(fp2_dbl_nc(E), E);                                                // 3E, 3 units
+    fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_sqr(fp2_add(t.y, t.z)), B), C));         // 2 Y Z
+    fp2 E2 = fp2_sqr(E);
+    fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
+    fp2 S = fp2_sqr(fp2_carry(fp2_add_nc(B, F)));
+    fp2 XY = fp2_mul(t.x, t.y);
+    fp2 x3 = fp2_carry(fp2_dbl_nc(fp2_mul(XY, fp2_carry(fp2_sub_nc(B, F)))));
+    fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));             // S - 12 E^2
+    fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(fp2_mul(B, H))));
+    t = g2_proj{x3, y3, z3};
+    return line_t{fp2_mul_fp(fp2_sub_nc(B, E), p.z3), fp2_mul_fp(X2, p.nxz3), fp2_mul_fp(H, p.y)};
+}
 
-// T <- T + Q, returns chord line through T and Q evaluated at P.
-BLS_MID line_t miller_add_step(g2_jac& t, const g2_jac& q, const g2_addpre& qp, const g1_pre& p) {
-    fp2 Z1Z1 = fp2_sqr(t.z);
-    fp2 U1 = fp2_mul(t.x, qp.z2);
-    fp2 U2 = fp2_mul(q.x, Z1Z1);
-    fp2 S1 = fp2_mul(t.y, qp.z3);
-    fp2 S2 = fp2_mul(fp2_mul(q.y, t.z), Z1Z1);
-    fp2 H = fp2_sub(U2, U1);
-    fp2 rr = fp2_sub(S2, S1);
-    fp2 HH = fp2_sqr(H);
-    fp2 HHH = fp2_mul(H, HH);
-    fp2 V = fp2_mul(U1, HH);
-    fp2 x3 = fp2_reduce(fp2_sub_nc(fp2_sub_nc(fp2_sqr(rr), HHH), fp2_dbl_nc(V)));
-    fp2 y3 = fp2_sub_nc(fp2_mul(rr, fp2_sub_nc(V, x3)), fp2_mul(S1, HHH));                                      // carried below
-    fp2 z3 = fp2_mul(fp2_mul(t.z, q.z), H);
-    // slope = rr / Z3.  line * (Z3 * Zq^3): (rr*Xq*Zq - Yq*Z3) - rr*Zq^3 * xp v + Z3*Zq^3 * yp vw
-    fp2 c0 = fp2_sub(fp2_mul(rr, fp2_mul(q.x, q.z)), fp2_mul(q.y, z3));
-    fp2 c1 = fp2_neg(fp2_mul(rr, qp.z3));
-    fp2 c2 = fp2_mul(z3, qp.z3);
-    t = g2_jac{x3, fp2_carry(y3), z3};
-    return line_scale(c0, c1, c2, p);
+// T <- T + Q (both homogeneous), returns the chord through T and Q evaluated at P, times (x2 - x1) Z1 Z2^2:
+//   (u X2 - v Y2)  -  u Z2 * xp v  +  v Z2 * yp vw,      u = Y2 Z1 - Y1 Z2,  v = X2 Z1 - X1 Z2
+BLS_MID line_t miller_add_step(g2_proj& t, const g2_proj& q, const g1_pre& p) {
+    fp2 Y1Z2 = fp2_mul(t.y, q.z), X1Z2 = fp2_mul(t.x, q.z), Z1Z2 = fp2_mul(t.z, q.z);
+    fp2 u = fp2_sub(fp2_mul(q.y, t.z), Y1Z2);
+    fp2 v = fp2_sub(fp2_mul(q.x, t.z), X1Z2);
+    fp2 uu = fp2_sqr(u), vv = fp2_sqr(v);
+    fp2 vvv = fp2_mul(v, vv);
+    fp2 R = fp2_mul(vv, X1Z2);
+    fp2 A = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_mul(uu, Z1Z2), vvv), fp2_dbl_nc(R)));
+    fp2 x3 = fp2_mul(v, A);
+    fp2 y3 = fp2_reduce(fp2_sub_nc(fp2_mul(u, fp2_sub_nc(R, A)), fp2_mul(vvv, Y1Z2)));
+    fp2 z3 = fp2_mul(vvv, Z1Z2);
+    fp2 c0 = fp2_carry(fp2_sub_nc(fp2_mul(u, q.x), fp2_mul(v, q.y)));
+    fp2 c1 = fp2_mul(u, q.z);
+    fp2 c2 = fp2_mul(v, q.z);
+    t = g2_proj{x3, y3, z3};
+    return line_t{fp2_mul_fp(c0, p.z3), fp2_neg(fp2_mul_fp(c1, p.xz)), fp2_mul_fp(c2, p.y)};
 }
 
 // Emits the 68 lines of pair (P, Q) through sink(step, line).  A pair with P or Q at infinity
 // contributes 1 (blst skips such pairs in the Miller loop).
 template <class Sink>
-BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& q, Sink&& sink) {
-    bool skip = jac_is_inf(pj) | jac_is_inf(q);
+BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
+    bool skip = jac_is_inf(pj) | jac_is_inf(qj);
     g1_pre p = g1_precompute(pj);
-    g2_addpre qp;
-    qp.z2 = fp2_sqr(q.z);
-    qp.z3 = fp2_mul(qp.z2, q.z);
-    g2_jac t = q;
+    g2_proj q = g2_to_proj(qj);
+    q = g2_proj{fp2_reduce(q.x), fp2_reduce(q.y), fp2_reduce(q.z)};
+    g2_proj t = q;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
         line_t l = miller_dbl_step(t, p);
         sink(s++, skip ? line_one() : l);
         if ((k::X_ABS >> bit) & 1) {
-            line_t a = miller_add_step(t, q, qp, p);
+            line_t a = miller_add_step(t, q, p);
             sink(s++, skip ? line_one() : a);
         }
     }
