@@ -166,6 +166,44 @@ BLS_HDN jac<F> jac_mul_u64(const aff<F>& p, uint64_t kk) {
     return acc;
 }
 
+// [k]P for a 64-bit scalar with signed 4-bit windows: k = sum d_j 16^j, d_j in [-8, 8].  In a wave the lanes hold
+// different scalars, so the bit-serial form above executes its conditional addition in (almost) every one of the
+// 64 iterations - some lane always has the bit set; here every lane adds once per window: 64 doublings +
+// 17 additions + a table of 1..8 times P (4 doublings, 3 mixed additions) instead of 64 + 64.
+template <class F>
+BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
+    jac<F> T[8];
+    T[0] = jac_from_aff(p);
+    T[1] = jac_dbl(T[0]);
+    T[2] = jac_add_aff(T[1], p);
+    T[3] = jac_dbl(T[1]);
+    T[4] = jac_add_aff(T[3], p);
+    T[5] = jac_dbl(T[2]);
+    T[6] = jac_add_aff(T[5], p);
+    T[7] = jac_dbl(T[3]);
+    // signed digits from the least significant end; dig[16] is the final carry (0 or 1)
+    int8_t dig[17];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        int32_t d = (int32_t)((kk >> (4 * j)) & 15u) + (int32_t)carry;
+        carry = d > 8;
+        dig[j] = (int8_t)(carry ? d - 16 : d);
+    }
+    dig[16] = (int8_t)carry;
+    jac<F> acc = jac_select(carry != 0, T[0], jac_inf<F>());
+    for (int j = 15; j >= 0; j--) {
+        acc = jac_dbl(jac_dbl(jac_dbl(jac_dbl(acc))));
+        int d = dig[j];
+        if (d != 0) {
+            jac<F> t = T[(d < 0 ? -d : d) - 1];
+            if (d < 0) t = jac_neg(t);
+            acc = jac_add(acc, t);
+        }
+    }
+    return acc;
+}
+
 // [k]P for Jacobian base
 template <class F>
 BLS_HDN jac<F> jac_mul_u64_jac(const jac<F>& p, uint64_t kk) {

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets
     const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
     g1_aff pk = ld_g1a_blst(w);
     if (aff_is_inf(pk)) atomicOr(flags, 1u);        // BLST_PK_IS_INFINITY -> update() false
-    g1_jac q = jac_mul_u64(pk, r[i]);
+    g1_jac q = jac_mul_u64_w4(pk, r[i]);
     soa_st_g1(P, stride, i, q);
 }
 

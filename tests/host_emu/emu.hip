@@ -27,6 +27,8 @@ void emu_sswu(const uint8_t* u, uint8_t* out) { g2_jac_store(out, sswu_g2(fp2_lo
 void emu_iso3(const uint8_t* in, uint8_t* out) { g2_jac_store(out, iso3_g2(g2_jac_load(in))); }
 void emu_hash_to_g2(const uint8_t* m, uint32_t n, const uint8_t* dst, uint32_t dn, uint8_t* out) { g2_jac_store(out, hash_to_g2(m, n, dst, dn)); }
 void emu_g1_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g1_jac_store(out, jac_mul_u64(g1_aff_load(p), k)); }
+void emu_g1_mul_u64_w4(const uint8_t* p, uint64_t k, uint8_t* out) { g1_jac_store(out, jac_mul_u64_w4(g1_aff_load(p), k)); }
+void emu_g2_mul_u64_w4(const uint8_t* p, uint64_t k, uint8_t* out) { g2_jac_store(out, jac_mul_u64_w4(g2_aff_load(p), k)); }
 void emu_g2_mul_u64(const uint8_t* p, uint64_t k, uint8_t* out) { g2_jac_store(out, jac_mul_u64(g2_aff_load(p), k)); }
 void emu_g1_mul_256(const uint8_t* p, const uint8_t* k32, uint8_t* out) {
     uint32_t kk[8];

@@ -64,6 +64,14 @@ def test_scalar_mul_and_add(emu):
         assert g1_jac_to_affine(r1) == o.g1_mul(p, kk)
         r2 = call(emu, "emu_g2_mul_u64", o.g2_to_blst_affine(q), ctypes.c_uint64(kk), outlen=288)
         assert g2_jac_to_affine(r2) == o.g2_mul(q, kk)
+    # signed 4-bit windows (k_pkmul): digit edge cases 8/9 (carry), all-ones, top carry, tiny scalars
+    for kk in [1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x99, 0xffffffffffffffff, 0x8888888888888888, 0x9999999999999999, 0x7fffffffffffffff,
+               1 << 63, rng.getrandbits(64), rng.getrandbits(64), rng.getrandbits(64)]:
+        r1 = call(emu, "emu_g1_mul_u64_w4", o.g1_to_blst_affine(p), ctypes.c_uint64(kk), outlen=144)
+        assert g1_jac_to_affine(r1) == o.g1_mul(p, kk), hex(kk)
+    for kk in [1, 9, 0xffffffffffffffff, rng.getrandbits(64)]:
+        r2 = call(emu, "emu_g2_mul_u64_w4", o.g2_to_blst_affine(q), ctypes.c_uint64(kk), outlen=288)
+        assert g2_jac_to_affine(r2) == o.g2_mul(q, kk), hex(kk)
     # 256-bit scalars (batch signer): affine base in G1, Jacobian base in G2
     for kk in [1, o.R - 1, rng.randrange(o.R), (1 << 255) + 12345]:
         k32 = kk.to_bytes(32, "little")
