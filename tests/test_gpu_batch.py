@@ -147,6 +147,31 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
     assert co.batch_verify(bytes(bad), rnd, nt) is False
 
 
+@pytest.mark.parametrize("n", [2048, 40960])
+def test_bucket_fold_of_the_signature_side(m, n):
+    """n >= 1024: the signatures are folded into digit buckets that become extra Miller pairs (4-bit digits below
+    40 000 tuples, 8-bit from there).  sum [r_i]S_i (folded from the buckets on demand) and the final GT value must
+    still be the C restatement's, also with infinity signatures in the batch (they contribute nothing)."""
+    import c_oracle as co
+    rec = bytearray(co.make_batch(n, seed=4242))
+    rnd = o.sha256(b"Mr F was here")
+    nt = 4096
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nt)
+    assert m.batchVerifyParallel(cache, bytes(rec), rnd) is True
+    ok, st = co.batch_verify(bytes(rec), rnd, nt, stages=True)
+    assert ok
+    assert o.g2_to_blst_affine(g2_jac_to_affine(cache.fetch(3, 288))) == st["aggsig"]
+    assert cache.fetch(4, 576) == st["gt"]
+    for i in (0, 777, n - 1):                                   # infinity signatures: all-zero affine image
+        rec[320 * i + 128:320 * i + 320] = bytes(192)
+    assert m.batchVerifyParallel(cache, bytes(rec), rnd) is False
+    ok, st = co.batch_verify(bytes(rec), rnd, nt, stages=True)
+    assert not ok
+    assert o.g2_to_blst_affine(g2_jac_to_affine(cache.fetch(3, 288))) == st["aggsig"]
+    assert cache.fetch(4, 576) == st["gt"]
+    cache.close()
+
+
 @pytest.mark.parametrize("n", [65537, 100003, 131072])
 def test_sizes_beyond_one_wave_per_simd(m, n):
     """More than 64 x 1024 tuples (several rounds of waves, side-stream path on/off): all-valid -> true,
