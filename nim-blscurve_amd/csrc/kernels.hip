@@ -2,16 +2,19 @@
 //
 // Pipeline for one batch of n SignatureSets (reference call stack: bls_batch_verifier.nim:296-371 ->
 // blst_min_pubkey_sig_core.nim:476-568,649-672 -> BLST):
-//   k_blind      one lane per blinding chain ("virtual thread"): r_i         (core :497-507,:545-556)
-//   k_hash       one lane per tuple: H_i = hash_to_G2(msg_i), Jacobian       (blst hash part)
-//   k_pkmul      one lane per tuple: [r_i]PK_i, Jacobian; infinity-pk flag    (blst pk part)
-//   k_sigmul     one lane per tuple: [r_i]S_i, wave-shuffle sum -> partials   (blst sig part)
-//   k_sigsum     partials -> AggrSign; appended as pair n with P = -G1        (finalverify's extra pair)
-//   k_lines      one lane per pair: 68 Miller lines -> HBM, step-major SoA    (miller_loop_n)
-//   k_lineprod   (step, pair-range) grid: per-lane sparse products, wave-shuffle Fp12 product tree
-//   k_lineprod2  per step: product of the range partials -> L_s
-//   k_tail       one wave, lane-parallel Fp12: Horner over the 68 L_s, conjugate, [shard merge],
-//                final exponentiation, == 1
+//   k_blind       one lane per blinding chain ("virtual thread"): r_i                  (core :497-507,:545-556)
+//   k_hash_map    two lanes per tuple: hash_to_field, SSWU + 3-isogeny of u_0 / u_1      (blst hash part)
+//   k_hash_clear  one lane per tuple: sum of the two mapped points, cofactor clearing; Jacobian H_i
+//   k_pkmul       one lane per tuple: [r_i]PK_i (signed 4-bit windows), Jacobian; infinity-pk flag (blst pk part)
+//   signature side (blst sig part + finalverify's extra pair):
+//     n >= 1024: k_sig_convert, k_msm_hist/scan/scatter (counting sort by digit of r_i), k_sig_bucket: bucket
+//                sums B_{w,d} -> extra Miller pairs (-[d 2^(cw)]G1, B_{w,d})
+//     n <  1024: k_sigmul ([r_i]S_i, wave-shuffle sum) + k_sigsum -> AggrSign, appended as pair n with P = -G1
+//   k_lines       one lane per pair: 68 Miller lines -> HBM, step-major SoA             (miller_loop_n)
+//   k_lineprod    (step, pair-range) grid: per-lane sparse products, wave-shuffle Fp12 product tree
+//   k_lineprod2   per step: product of the range partials -> L_s
+//   k_tail        one wave, lane-parallel Fp12: Horner over the 68 L_s, conjugate, [shard merge],
+//                 final exponentiation, == 1
 // Intermediates live in HBM as structure-of-arrays of 16-byte limb groups so that lane i's
 // loads/stores of one limb group are contiguous across the wave (coalesced dwordx4).
 #include <hip/hip_runtime.h>
@@ -221,23 +224,6 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
         } while (r == 0);
         r_out[off + j - tuple_base] = r;
     }
-}
-
-__global__ void __launch_bounds__(WAVE) k_hash(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ H, size_t stride) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint8_t msg[32];
-    const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t w = mw[j];
-        msg[4 * j] = (uint8_t)w;
-        msg[4 * j + 1] = (uint8_t)(w >> 8);
-        msg[4 * j + 2] = (uint8_t)(w >> 16);
-        msg[4 * j + 3] = (uint8_t)(w >> 24);
-    }
-    g2_jac h = hash_to_g2(msg, 32, dst.b, dst.len);
-    soa_st_g2(H, stride, i, h);
 }
 
 // Batch form of hash-to-G2 in two kernels.  k_hash_map: TWO lanes per message, lane j maps u_j (SSWU + 3-isogeny:
