@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
+__global__ void __launch_bounds__(WAVE) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
     if (i >= n) return;
     uint8_t msg[32];
@@ -360,7 +360,8 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
         for (uint32_t j = 1; j < m; j++) {
             size_t j0 = first + (size_t)j * WAVE;
             if (j0 >= npairs) break;
-            f = fp12_mul_by_line(f, ld_line(j0));
+            line_ops_lds::park(ld_line(j0));
+            f = fp12_mul_by_line_ops(f, line_ops_lds{});
         }
     }
     f = fp12_reduce(f);

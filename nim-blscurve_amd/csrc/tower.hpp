@@ -94,18 +94,21 @@ struct line_t {
 // Inputs: f and the line coefficients carried (at most 1 limb unit).  The result is carried, NOT reduced:
 // every coefficient is a sum of at most 8 products (|v| < 16p), which is stable under repeated multiplication
 // by reduced lines.  Reduce (fp12_reduce) before a general fp12_mul.
-BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
+// The line operands are reached through a provider so that the device can keep them parked in LDS:
+//   L.mul_l0(x) = x * l0, L.mul_l1, L.mul_l2, L.mul_m1 (m1 = l1 + l2), L.mul_l0l1 (x * (l0 + l1)), L.mul_l0m1.
+template <class LineOps>
+BLS_MID fp12 fp12_mul_by_line_ops(const fp12& f, const LineOps& L) {
     const fp6 &a = f.c0, &b = f.c1;
-    fp2 a0l0 = fp2_mul(a.a0, l.l0), a1l1 = fp2_mul(a.a1, l.l1);
-    fp2 t0c1 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_add_nc(a.a0, a.a1), fp2_add_nc(l.l0, l.l1)), a0l0), a1l1);      // 3 units
-    fp2 t0c0 = fp2_add_nc(a0l0, fp2_mul_xi_nc(fp2_mul(a.a2, l.l1)));                                            // 3
-    fp2 t0c2 = fp2_add_nc(a1l1, fp2_mul(a.a2, l.l0));                                                           // 2
-    fp2 t1a0 = fp2_mul_xi(fp2_mul(b.a2, l.l2)), t1a1 = fp2_mul(b.a0, l.l2), t1a2 = fp2_mul(b.a1, l.l2);          // 1 each
-    fp2 s0 = fp2_add_nc(a.a0, b.a0), s1 = fp2_add_nc(a.a1, b.a1), s2 = fp2_add_nc(a.a2, b.a2), m1 = fp2_add_nc(l.l1, l.l2);
-    fp2 s0l0 = fp2_mul(s0, l.l0), s1m1 = fp2_mul(s1, m1);
-    fp2 sc1 = fp2_sub_nc(fp2_sub_nc(fp2_mul(fp2_carry(fp2_add_nc(s0, s1)), fp2_carry(fp2_add_nc(l.l0, m1))), s0l0), s1m1);   // 3
-    fp2 sc0 = fp2_add_nc(s0l0, fp2_mul_xi_nc(fp2_mul(s2, m1)));                                                 // 3
-    fp2 sc2 = fp2_add_nc(s1m1, fp2_mul(s2, l.l0));                                                              // 2
+    fp2 a0l0 = L.mul_l0(a.a0), a1l1 = L.mul_l1(a.a1);
+    fp2 t0c1 = fp2_sub_nc(fp2_sub_nc(L.mul_l0l1(fp2_add_nc(a.a0, a.a1)), a0l0), a1l1);                           // 3 units
+    fp2 t0c0 = fp2_add_nc(a0l0, fp2_mul_xi_nc(L.mul_l1(a.a2)));                                                 // 3
+    fp2 t0c2 = fp2_add_nc(a1l1, L.mul_l0(a.a2));                                                                // 2
+    fp2 t1a0 = fp2_mul_xi(L.mul_l2(b.a2)), t1a1 = L.mul_l2(b.a0), t1a2 = L.mul_l2(b.a1);                         // 1 each
+    fp2 s0 = fp2_add_nc(a.a0, b.a0), s1 = fp2_add_nc(a.a1, b.a1), s2 = fp2_add_nc(a.a2, b.a2);
+    fp2 s0l0 = L.mul_l0(s0), s1m1 = L.mul_m1(s1);
+    fp2 sc1 = fp2_sub_nc(fp2_sub_nc(L.mul_l0m1(fp2_carry(fp2_add_nc(s0, s1))), s0l0), s1m1);                     // 3
+    fp2 sc0 = fp2_add_nc(s0l0, fp2_mul_xi_nc(L.mul_m1(s2)));                                                    // 3
+    fp2 sc2 = fp2_add_nc(s1m1, L.mul_l0(s2));                                                                   // 2
     fp12 r;
     r.c1.a0 = fp2_carry(fp2_sub_nc(fp2_sub_nc(sc0, t0c0), t1a0));             // c1 = s - t0 - t1: 3 + 3 + 1
     r.c1.a1 = fp2_carry(fp2_sub_nc(fp2_sub_nc(sc1, t0c1), t1a1));
@@ -115,6 +118,43 @@ BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     r.c0.a2 = fp2_carry(fp2_add_nc(t0c2, t1a1));
     return r;
 }
+// line operands held in registers
+struct line_ops_regs {
+    line_t l;
+    fp2 m1;
+    BLS_HD fp2 mul_l0(const fp2& x) const { return fp2_mul(x, l.l0); }
+    BLS_HD fp2 mul_l1(const fp2& x) const { return fp2_mul(x, l.l1); }
+    BLS_HD fp2 mul_l2(const fp2& x) const { return fp2_mul(x, l.l2); }
+    BLS_HD fp2 mul_m1(const fp2& x) const { return fp2_mul(x, m1); }
+    BLS_HD fp2 mul_l0l1(const fp2& x) const { return fp2_mul(x, fp2_add_nc(l.l0, l.l1)); }
+    BLS_HD fp2 mul_l0m1(const fp2& x) const { return fp2_mul(x, fp2_carry(fp2_add_nc(l.l0, m1))); }
+};
+BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
+    return fp12_mul_by_line_ops(f, line_ops_regs{l, fp2_add_nc(l.l1, l.l2)});
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// line operands parked in LDS slots 1..4 (l0, l1, l2, l1 + l2) by line_ops_lds::park: they hold no registers
+// between their uses; the two operand sums are rebuilt from LDS right before their single use
+struct line_ops_lds {
+    static __device__ __forceinline__ void park(const line_t& l) {
+        fp2_lds_put(1, l.l0);
+        fp2_lds_put(2, l.l1);
+        fp2_lds_put(3, l.l2);
+        fp2_lds_put(4, fp2_add_nc(l.l1, l.l2));
+    }
+    __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_slot(x, 1); }
+    __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_slot(x, 2); }
+    __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_slot(x, 3); }
+    __device__ __forceinline__ fp2 mul_m1(const fp2& x) const { return fp2_mul_slot(x, 4); }
+    __device__ __forceinline__ fp2 mul_l0l1(const fp2& x) const { return fp2_mul(x, fp2_add_nc(fp2_lds_get(1), fp2_lds_get(2))); }
+    __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const { return fp2_mul(x, fp2_carry(fp2_add_nc(fp2_lds_get(1), fp2_lds_get(4)))); }
+};
+#else
+// host pass of a .hip translation unit: kernels are parsed, never run
+struct line_ops_lds : line_ops_regs {
+    static void park(const line_t&) {}
+};
+#endif
 BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
 
 BLS_HD fp12 fp12_from_line(const line_t& l) {
