@@ -578,17 +578,20 @@ __device__ __forceinline__ bls_u32x32 fp2_pack(const fp& c0, const fp& c1) {
 // wave's accesses are conflict-free).  Registers carry only 32 argument words; the rest would travel on the
 // stack, i.e. through scratch memory, which at 1024 waves x 13 products per line was ~6 GB of HBM writes per
 // k_lineprod launch.  Every kernel of this library runs one wave per workgroup, so the slot is wave-private.
-// Slot 0 is the hand-over slot of fp2_mul; slots 1..4 hold operands that a kernel parks for repeated use (k_lineprod:
-// the line coefficients, which then occupy no registers at all).
-constexpr int BLS_LDS_SLOTS = 5;
-static __shared__ uint4 bls_xchg[BLS_LDS_SLOTS * 7 * 64];
-__device__ __noinline__ bls_u32x32 fp2_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27, uint32_t slot) {
+// bls_xchg is the hand-over slot of fp2_mul; a kernel may park operands it uses repeatedly in LDS slots of its own
+// (k_lineprod: the line coefficients, which then occupy no registers at all) and multiply by them with
+// fp2_mul_lds.  A slot is 7 groups of 64 lanes x 16 bytes.
+typedef uint32_t bls_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bls_u32x4 bls_lds_u32x4;
+constexpr int BLS_LDS_SLOT = 7 * 64;
+static __shared__ bls_u32x4 bls_xchg[BLS_LDS_SLOT];
+__device__ __noinline__ bls_u32x32 fp2_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27, const bls_lds_u32x4* slot) {
     fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, y0, y1, nx1;
     uint32_t yw[28];
-    const uint32_t lane = (threadIdx.x & 63u) + slot * (7 * 64);
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int q = 0; q < 7; q++) {
-        uint4 v = bls_xchg[q * 64 + lane];
+        bls_u32x4 v = slot[q * 64 + lane];
         yw[4 * q] = v.x; yw[4 * q + 1] = v.y; yw[4 * q + 2] = v.z; yw[4 * q + 3] = v.w;
     }
 #pragma unroll
@@ -624,8 +627,8 @@ __device__ __forceinline__ fp2 fp2_unpack(const bls_u32x32& r) {
     }
     return o;
 }
-__device__ __forceinline__ void fp2_lds_put(uint32_t slot, const fp2& b) {
-    const uint32_t lane = (threadIdx.x & 63u) + slot * (7 * 64);
+__device__ __forceinline__ void fp2_lds_put(bls_lds_u32x4* slot, const fp2& b) {
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t yw[28];
 #pragma unroll
     for (int i = 0; i < FP_N; i++) {
@@ -633,14 +636,17 @@ __device__ __forceinline__ void fp2_lds_put(uint32_t slot, const fp2& b) {
         yw[FP_N + i] = b.c1.l[i];
     }
 #pragma unroll
-    for (int q = 0; q < 7; q++) bls_xchg[q * 64 + lane] = make_uint4(yw[4 * q], yw[4 * q + 1], yw[4 * q + 2], yw[4 * q + 3]);
+    for (int q = 0; q < 7; q++) {
+        bls_u32x4 v = {yw[4 * q], yw[4 * q + 1], yw[4 * q + 2], yw[4 * q + 3]};
+        slot[q * 64 + lane] = v;
+    }
 }
-__device__ __forceinline__ fp2 fp2_lds_get(uint32_t slot) {
-    const uint32_t lane = (threadIdx.x & 63u) + slot * (7 * 64);
+__device__ __forceinline__ fp2 fp2_lds_get(const bls_lds_u32x4* slot) {
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t yw[28];
 #pragma unroll
     for (int q = 0; q < 7; q++) {
-        uint4 v = bls_xchg[q * 64 + lane];
+        bls_u32x4 v = slot[q * 64 + lane];
         yw[4 * q] = v.x; yw[4 * q + 1] = v.y; yw[4 * q + 2] = v.z; yw[4 * q + 3] = v.w;
     }
     fp2 r;
@@ -651,13 +657,14 @@ __device__ __forceinline__ fp2 fp2_lds_get(uint32_t slot) {
     }
     return r;
 }
-// a * (the Fp2 value parked in LDS slot `slot`)
-__device__ __forceinline__ fp2 fp2_mul_slot(const fp2& a, uint32_t slot) {
+// a * (the Fp2 value parked in the LDS slot)
+__device__ __forceinline__ fp2 fp2_mul_lds(const fp2& a, const bls_lds_u32x4* slot) {
     return fp2_unpack(fp2_mul_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13], slot));
 }
 __device__ __forceinline__ fp2 fp2_mul(const fp2& a, const fp2& b) {
-    fp2_lds_put(0, b);
-    return fp2_mul_slot(a, 0);
+    bls_lds_u32x4* x = (bls_lds_u32x4*)bls_xchg;
+    fp2_lds_put(x, b);
+    return fp2_mul_lds(a, x);
 }
 __device__ __forceinline__ fp2 fp2_sqr(const fp2& a) {
     return fp2_unpack(fp2_sqr_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13]));

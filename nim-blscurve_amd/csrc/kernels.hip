@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-__global__ void __launch_bounds__(WAVE) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
+__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
     if (i >= n) return;
     uint8_t msg[32];
@@ -355,13 +355,19 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
         return line_t{fp2_select(v, l.l0, fp2_one()), fp2_select(v, l.l1, fp2_zero()), fp2_select(v, l.l2, fp2_zero())};
     };
     fp12 f = fp12_one();
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 line_slots[4 * BLS_LDS_SLOT];              // 28 KB: with the 7 KB hand-over slot 35 of the 40 KB a wave may use
+    line_ops_lds lops{(bls_lds_u32x4*)line_slots};
+#else
+    line_ops_lds lops{};
+#endif
     if (first < npairs) {
         f = fp12_from_line(ld_line(first));
         for (uint32_t j = 1; j < m; j++) {
             size_t j0 = first + (size_t)j * WAVE;
             if (j0 >= npairs) break;
-            line_ops_lds::park(ld_line(j0));
-            f = fp12_mul_by_line_ops(f, line_ops_lds{});
+            lops.park(ld_line(j0));
+            f = fp12_mul_by_line_ops(f, lops);
         }
     }
     f = fp12_reduce(f);

@@ -133,26 +133,29 @@ BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
     return fp12_mul_by_line_ops(f, line_ops_regs{l, fp2_add_nc(l.l1, l.l2)});
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-// line operands parked in LDS slots 1..4 (l0, l1, l2, l1 + l2) by line_ops_lds::park: they hold no registers
+// line operands parked in four LDS slots of the kernel (l0, l1, l2, l1 + l2) by park(): they hold no registers
 // between their uses; the two operand sums are rebuilt from LDS right before their single use
 struct line_ops_lds {
-    static __device__ __forceinline__ void park(const line_t& l) {
-        fp2_lds_put(1, l.l0);
-        fp2_lds_put(2, l.l1);
-        fp2_lds_put(3, l.l2);
-        fp2_lds_put(4, fp2_add_nc(l.l1, l.l2));
+    bls_lds_u32x4* base;           // 4 slots
+    __device__ __forceinline__ void park(const line_t& l) const {
+        fp2_lds_put(base, l.l0);
+        fp2_lds_put(base + BLS_LDS_SLOT, l.l1);
+        fp2_lds_put(base + 2 * BLS_LDS_SLOT, l.l2);
+        fp2_lds_put(base + 3 * BLS_LDS_SLOT, fp2_add_nc(l.l1, l.l2));
     }
-    __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_slot(x, 1); }
-    __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_slot(x, 2); }
-    __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_slot(x, 3); }
-    __device__ __forceinline__ fp2 mul_m1(const fp2& x) const { return fp2_mul_slot(x, 4); }
-    __device__ __forceinline__ fp2 mul_l0l1(const fp2& x) const { return fp2_mul(x, fp2_add_nc(fp2_lds_get(1), fp2_lds_get(2))); }
-    __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const { return fp2_mul(x, fp2_carry(fp2_add_nc(fp2_lds_get(1), fp2_lds_get(4)))); }
+    __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_lds(x, base); }
+    __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_lds(x, base + BLS_LDS_SLOT); }
+    __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_lds(x, base + 2 * BLS_LDS_SLOT); }
+    __device__ __forceinline__ fp2 mul_m1(const fp2& x) const { return fp2_mul_lds(x, base + 3 * BLS_LDS_SLOT); }
+    __device__ __forceinline__ fp2 mul_l0l1(const fp2& x) const { return fp2_mul(x, fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT))); }
+    __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const {
+        return fp2_mul(x, fp2_carry(fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + 3 * BLS_LDS_SLOT))));
+    }
 };
 #else
 // host pass of a .hip translation unit: kernels are parsed, never run
 struct line_ops_lds : line_ops_regs {
-    static void park(const line_t&) {}
+    void park(const line_t&) const {}
 };
 #endif
 BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
