@@ -172,15 +172,17 @@ BLS_HDN jac<F> jac_mul_u64(const aff<F>& p, uint64_t kk) {
 // 17 additions + a table of 1..8 times P (4 doublings, 3 mixed additions) instead of 64 + 64.
 template <class F>
 BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
+    // T[i] = (i + 1) P.  One copy of the doubling and of the mixed addition in a loop: unrolled, this function
+    // was 84 KB of code against a 64 KB instruction cache.
     jac<F> T[8];
     T[0] = jac_from_aff(p);
-    T[1] = jac_dbl(T[0]);
-    T[2] = jac_add_aff(T[1], p);
-    T[3] = jac_dbl(T[1]);
-    T[4] = jac_add_aff(T[3], p);
-    T[5] = jac_dbl(T[2]);
-    T[6] = jac_add_aff(T[5], p);
-    T[7] = jac_dbl(T[3]);
+#pragma clang loop unroll(disable)
+    for (int i = 1; i < 8; i++) {
+        if (i & 1)
+            T[i] = jac_dbl(T[i >> 1]);              // 2, 4, 6, 8 times P
+        else
+            T[i] = jac_add_aff(T[i - 1], p);        // 3, 5, 7 times P
+    }
     // signed digits from the least significant end; dig[16] is the final carry (0 or 1)
     int8_t dig[17];
     uint32_t carry = 0;
@@ -192,8 +194,10 @@ BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
     }
     dig[16] = (int8_t)carry;
     jac<F> acc = jac_select(carry != 0, T[0], jac_inf<F>());
+#pragma clang loop unroll(disable)
     for (int j = 15; j >= 0; j--) {
-        acc = jac_dbl(jac_dbl(jac_dbl(jac_dbl(acc))));
+#pragma clang loop unroll(disable)
+        for (int k4 = 0; k4 < 4; k4++) acc = jac_dbl(acc);
         int d = dig[j];
         if (d != 0) {
             jac<F> t = T[(d < 0 ? -d : d) - 1];
