@@ -1,12 +1,34 @@
 #!/bin/bash
 # Builds the C-ABI shared library (HIP kernels for gfx950) in-tree.
+#
+#   device side:  hipcc -S  ->  tools/align_isa.py (every 8-byte instruction 8-byte aligned, see its header)
+#                 ->  assemble  ->  link the code object  ->  bundle
+#   host side:    hipcc --cuda-host-only with the bundle embedded (-fcuda-include-gpubinary), linked to libamdhip64
+# This is what `hipcc -shared` does in one go (see `hipcc -###`), with the post-pass spliced in between.  If any
+# step of the spliced pipeline fails, the plain one-step hipcc build is used instead (same code, unaligned).
 set -e
 cd "$(dirname "$0")"
 OUT=libblscurve_mi355x.so
-if [ "$1" != "-f" ] && [ -f $OUT ] && [ -z "$(find csrc ../include -newer $OUT -type f)" ]; then
+if [ "$1" != "-f" ] && [ -f $OUT ] && [ -z "$(find csrc ../include tools/align_isa.py build.sh -newer $OUT -type f)" ]; then
   exit 0
 fi
+LLVM=/opt/rocm/lib/llvm/bin
 # --gpu-max-threads-per-block=64: every kernel is one wave per workgroup; this also gives the out-of-line device
 # functions the full 512-register (VGPR+AGPR) budget instead of the 128-VGPR default, so they stop spilling to scratch
-hipcc -O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64 -fPIC -shared csrc/kernels.hip -o $OUT.tmp
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64"
+B=build
+mkdir -p $B
+aligned_build() {
+  hipcc $FLAGS --cuda-device-only -S -o $B/dev.s csrc/kernels.hip || return 1
+  python3 tools/align_isa.py $B/dev.s $B/dev_aligned.s --clang $LLVM/clang --objdump $LLVM/llvm-objdump || return 1
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $B/dev_aligned.s -o $B/dev.o || return 1
+  $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $B/dev.co $B/dev.o || return 1
+  $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 \
+      -input=/dev/null -input=$B/dev.co -output=$B/dev.hipfb || return 1
+  hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $B/dev.hipfb -fPIC -shared csrc/kernels.hip -o $OUT.tmp || return 1
+}
+if [ "$BLS_NO_ALIGN" = "1" ] || ! aligned_build; then
+  echo "build.sh: plain hipcc build (no alignment post-pass)" >&2
+  hipcc $FLAGS -fPIC -shared csrc/kernels.hip -o $OUT.tmp
+fi
 mv $OUT.tmp $OUT
