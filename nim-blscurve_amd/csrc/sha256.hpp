@@ -16,7 +16,7 @@ BLS_CONST uint32_t SHA_K[64] = {
 BLS_HD uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
 // one compression; w[16] = big-endian words of the block (clobbered)
-BLS_HD void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
+BLS_HD void sha256_compress_core(uint32_t (&h)[8], uint32_t (&w)[16]) {
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
 #pragma unroll
     for (int i = 0; i < 64; i++) {
@@ -36,6 +36,30 @@ BLS_HD void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ONE out-of-line copy of the 64 rounds, state and block in registers (24 scalar arguments, result in v0..v7):
+// inlined at every block of expand_message_xmd the rounds made hash_to_field 280 KB of straight-line code, which
+// k_hash_map spent a fifth of its cycles fetching.
+typedef uint32_t bls_u32x8 __attribute__((ext_vector_type(8)));
+__device__ __noinline__ bls_u32x8 sha256_compress_regs(uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t h4, uint32_t h5, uint32_t h6,
+                                                       uint32_t h7, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5,
+                                                       uint32_t w6, uint32_t w7, uint32_t w8, uint32_t w9, uint32_t w10, uint32_t w11, uint32_t w12,
+                                                       uint32_t w13, uint32_t w14, uint32_t w15) {
+    uint32_t h[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+    uint32_t w[16] = {w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
+    sha256_compress_core(h, w);
+    bls_u32x8 r = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+    return r;
+}
+__device__ __forceinline__ void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
+    bls_u32x8 r = sha256_compress_regs(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9],
+                                       w[10], w[11], w[12], w[13], w[14], w[15]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = r[i];
+}
+#else
+BLS_HD void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) { sha256_compress_core(h, w); }
+#endif
 
 BLS_HD void sha256_init(uint32_t (&h)[8]) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
