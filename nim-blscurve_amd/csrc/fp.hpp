@@ -293,6 +293,18 @@ __device__ __noinline__ fp fp_sqr_regs(uint32_t a0, uint32_t a1, uint32_t a2, ui
     fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
     return fp_sqr_core(a);
 }
+// n squarings in one call (n >= 1): the exponentiations square 4 times per window, and a call costs the argument
+// moves plus an instruction-fetch bubble at the jump and at the return
+__device__ __noinline__ fp fp_sqr_n_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                         uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t n) {
+    fp a{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+#pragma clang loop unroll(disable)
+    for (uint32_t i = 0; i < n; i++) a = fp_sqr_core(a);
+    return a;
+}
+__device__ __forceinline__ fp fp_sqr_n(const fp& a, uint32_t n) {
+    return fp_sqr_n_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], n);
+}
 __device__ __forceinline__ fp fp_sqr(const fp& a) {
     return fp_sqr_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13]);
 }
@@ -323,6 +335,11 @@ __host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
     }
 #endif
     return fp_sqr_core(a);
+}
+__host__ __device__ inline fp fp_sqr_n(const fp& a, uint32_t n) {
+    fp r = a;
+    for (uint32_t i = 0; i < n; i++) r = fp_sqr(r);
+    return r;
 }
 __host__ __device__ __noinline__ inline fp fp_dot2(const fp& a, const fp& b, const fp& c, const fp& d) {
 #if defined(BLS_TRACK_BOUNDS)
@@ -471,12 +488,7 @@ BLS_HDN fp fp_pow(const fp& a, const uint32_t (&e)[12]) {
     bool started = false;
     for (int w = 95; w >= 0; w--) {
         uint32_t nib = (e[w >> 3] >> ((w & 7) * 4)) & 0xf;
-        if (started) {
-            r = fp_sqr(r);
-            r = fp_sqr(r);
-            r = fp_sqr(r);
-            r = fp_sqr(r);
-        }
+        if (started) r = fp_sqr_n(r, 4);
         if (nib) {
             r = started ? fp_mul(r, tab[nib]) : tab[nib];
             started = true;
