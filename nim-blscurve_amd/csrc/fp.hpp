@@ -479,36 +479,26 @@ BLS_HD void fp_to_blst(uint32_t (&w)[12], const fp& a) {
 
 // a^e for a 384-bit exponent given as 12 LE 32-bit words; fixed 4-bit window, not constant time
 // (nothing secret on this path: public keys, messages, signatures and public blinding scalars).
-BLS_HDN fp fp_pow(const fp& a, const uint32_t (&e)[12]) {
-    fp tab[16];
-    tab[0] = fp_one();
-    tab[1] = a;
-    for (int i = 2; i < 16; i++) tab[i] = fp_mul(tab[i - 1], a);
-    fp r = fp_one();
-    bool started = false;
-    for (int w = 95; w >= 0; w--) {
-        uint32_t nib = (e[w >> 3] >> ((w & 7) * 4)) & 0xf;
-        if (started) r = fp_sqr_n(r, 4);
-        if (nib) {
-            r = started ? fp_mul(r, tab[nib]) : tab[nib];
-            started = true;
-        }
+// a^e for one of the two fixed exponents, by its 5-bit sliding-window schedule (constants.hpp: pairs of
+// (squarings, odd multiplier)): 379 squarings + 67 multiplications + 16 for the table of odd powers.
+BLS_HDN fp fp_pow_sched(const fp& a, const uint8_t (*sched)[2], int len) {
+    fp tab[16];                                  // a^1, a^3, ..., a^31
+    tab[0] = a;
+    fp a2 = fp_sqr(a);
+    for (int i = 1; i < 16; i++) tab[i] = fp_mul(tab[i - 1], a2);
+    fp r = tab[sched[0][1] >> 1];
+    for (int j = 1; j < len; j++) {
+        r = fp_sqr_n(r, sched[j][0]);
+        uint32_t v = sched[j][1];
+        if (v) r = fp_mul(r, tab[v >> 1]);
     }
     return r;
 }
 
-BLS_HD fp fp_inv(const fp& a) {
-    const uint32_t e[12] = {k::EXP_PM2[0], k::EXP_PM2[1], k::EXP_PM2[2], k::EXP_PM2[3], k::EXP_PM2[4], k::EXP_PM2[5],
-                            k::EXP_PM2[6], k::EXP_PM2[7], k::EXP_PM2[8], k::EXP_PM2[9], k::EXP_PM2[10], k::EXP_PM2[11]};
-    return fp_pow(a, e);
-}
+BLS_HD fp fp_inv(const fp& a) { return fp_pow_sched(a, k::SW_PM2, k::SW_PM2_LEN); }
 
 // a^((p-3)/4): for a QR this is 1/sqrt(a); for a non-residue (a*t)^2 = -a.
-BLS_HD fp fp_recip_sqrt_pow(const fp& a) {
-    const uint32_t e[12] = {k::EXP_PM3D4[0], k::EXP_PM3D4[1], k::EXP_PM3D4[2], k::EXP_PM3D4[3], k::EXP_PM3D4[4], k::EXP_PM3D4[5],
-                            k::EXP_PM3D4[6], k::EXP_PM3D4[7], k::EXP_PM3D4[8], k::EXP_PM3D4[9], k::EXP_PM3D4[10], k::EXP_PM3D4[11]};
-    return fp_pow(a, e);
-}
+BLS_HD fp fp_recip_sqrt_pow(const fp& a) { return fp_pow_sched(a, k::SW_PM3D4, k::SW_PM3D4_LEN); }
 
 // 48 little-endian bytes (blst_fp memory image) <-> fp   (host-side tests and byte-addressed inputs)
 BLS_HD fp fp_load_le(const uint8_t* p) {
