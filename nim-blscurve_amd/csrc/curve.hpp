@@ -126,7 +126,7 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
 // through the by-value wrapper jac_add below so that only its private copies have their address taken and
 // the caller's own (often loop-carried) points stay in registers.
 template <class F>
-BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) {
+BLS_MID jac<F> jac_add_body(const jac<F>& p, const jac<F>& q) {
     bool p_inf = jac_is_inf(p);
     bool q_inf = jac_is_inf(q);
     F Z1Z1 = f_sqr(p.z);
@@ -151,6 +151,8 @@ BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) {
     return r;
 }
 
+template <class F>
+BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) { return jac_add_body(p, q); }
 template <class F>
 BLS_HD jac<F> jac_add(jac<F> p, jac<F> q) { return jac_add_impl(p, q); }
 
@@ -202,7 +204,7 @@ BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
         if (d != 0) {
             jac<F> t = T[(d < 0 ? -d : d) - 1];
             if (d < 0) t = jac_neg(t);
-            acc = jac_add(acc, t);
+            acc = jac_add_body(acc, t);          // inlined: one copy in this loop, operands stay in registers
         }
     }
     return acc;
