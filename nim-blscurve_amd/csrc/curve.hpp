@@ -216,7 +216,7 @@ BLS_HDN jac<F> jac_mul_u64_jac(const jac<F>& p, uint64_t kk) {
     jac<F> acc = jac_inf<F>();
     for (int i = 63; i >= 0; i--) {
         acc = jac_dbl(acc);
-        if ((kk >> i) & 1) acc = jac_add(acc, p);
+        if ((kk >> i) & 1) acc = jac_add_body(acc, p);      // inlined (one copy): no operands through memory
     }
     return acc;
 }
@@ -237,7 +237,7 @@ BLS_HDN jac<F> jac_mul_256_jac(const jac<F>& p, const uint32_t (&kk)[8]) {
     jac<F> acc = jac_inf<F>();
     for (int i = 255; i >= 0; i--) {
         acc = jac_dbl(acc);
-        if ((kk[i >> 5] >> (i & 31)) & 1) acc = jac_add(acc, p);
+        if ((kk[i >> 5] >> (i & 31)) & 1) acc = jac_add_body(acc, p);
     }
     return acc;
 }
