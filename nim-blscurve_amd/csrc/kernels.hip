@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
+        acc = jac_add_body(acc, o);
     }
     if (threadIdx.x == 0) {
         st_g1_int(part + (size_t)blockIdx.x * G1W, acc);
@@ -666,11 +666,11 @@ __global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts
 __global__ void __launch_bounds__(WAVE) k_g1_sum2(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ out) {
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) {
-        acc = jac_add(acc, ld_g1_int(part + (size_t)j * G1W));
+        acc = jac_add_body(acc, ld_g1_int(part + (size_t)j * G1W));
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
+        acc = jac_add_body(acc, o);
     }
     if (threadIdx.x == 0) st_g1_blst(out, acc);        // blst_p1 image
 }
@@ -838,14 +838,15 @@ __global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ b
     g1_jac S = jac_inf<fp>(), T = jac_inf<fp>();
     for (uint32_t j = L; j-- > 0;) {
         g1_jac B = soa_ld_g1(buckets, total, ((size_t)w << c) | (b0 + j));
-        S = jac_add(S, B);
-        T = jac_add(T, S);            // T = sum (j+1) * B_{b0+j}
+        S = jac_add_body(S, B);       // inlined additions: the running sums stay in registers
+        T = jac_add_body(T, S);       // T = sum (j+1) * B_{b0+j}
     }
-    // W = T + (b0 - 1) * S
+    // W = T + (b0 - 1) * S, b0 < 2^c
     g1_jac acc = jac_inf<fp>();
-    for (int i = 31; i >= 0; i--) {
+#pragma clang loop unroll(disable)
+    for (int i = (int)c - 1; i >= 0; i--) {
         acc = jac_dbl(acc);
-        if ((b0 >> i) & 1) acc = jac_add(acc, S);
+        if ((b0 >> i) & 1) acc = jac_add_body(acc, S);
     }
     acc = jac_add(acc, jac_neg(S));
     acc = jac_add(acc, T);
@@ -855,10 +856,10 @@ __global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ b
 __global__ void __launch_bounds__(WAVE) k_msm_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t* __restrict__ part) {
     uint32_t w = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
     g1_jac acc = jac_inf<fp>();
-    for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit) acc = jac_add(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
+    for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit) acc = jac_add_body(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
+        acc = jac_add_body(acc, o);
     }
     if (threadIdx.x == 0) {
         st_g1_int(part + ((size_t)w * nsplit + sp) * G1W, acc);
@@ -869,11 +870,11 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
     uint32_t w = blockIdx.x;
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) {
-        acc = jac_add(acc, ld_g1_int(part + ((size_t)w * nsplit + j) * G1W));
+        acc = jac_add_body(acc, ld_g1_int(part + ((size_t)w * nsplit + j) * G1W));
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
+        acc = jac_add_body(acc, o);
     }
     if (threadIdx.x == 0) {
         uint32_t sh = msm_win_off(W, w);
