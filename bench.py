@@ -2,7 +2,7 @@
 """Headline benchmark: BLS batch signature verifications / second on MI355X.
 
 A step = one batchVerify of a 65 536-tuple batch per GPU (the size BASELINE.json's target is quoted
-on), inputs resident in HBM before the timed region; `--inflight` (default 3) independent caller contexts keep
+on), inputs resident in HBM before the timed region; `--inflight` (default 4) independent caller contexts keep
 that many batches in flight so the serial tail of one overlaps the wide kernels of another.  N > 1: one process per GPU, each verifies its
 own 65 536-tuple shard of one global batch (weak scaling); the only exchange is an all_gather of the
 576-byte committed Fp12 state + ok flag per rank (RCCL), then one final exponentiation on rank 0.
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=65536, help="tuples per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="tuples in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--inflight", type=int, default=3, help="batches kept in flight per GPU (independent caller contexts)")
+    ap.add_argument("--inflight", type=int, default=4, help="batches kept in flight per GPU (independent caller contexts)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the fastAggregateVerify / MSM side measurements")
     a = ap.parse_args()
