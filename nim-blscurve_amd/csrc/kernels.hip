@@ -865,6 +865,30 @@ __global__ void __launch_bounds__(WAVE) k_msm_winpart(const uint4* __restrict__ 
         st_g1_int(part + ((size_t)w * nsplit + sp) * G1W, acc);
     }
 }
+// Lane-parallel G1 doubling for the serial doubling chains: every lane holds the same point; the three independent
+// products of each of the first two rounds of dbl-2009-l run in lanes 0, 1, 2 of ONE multiplier call and are then
+// broadcast (3 multiplication times per doubling instead of 7).  Same carry/reduce pattern as jac_dbl.
+__device__ __forceinline__ fp fp_bcast(const fp& a, int src) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
+    return r;
+}
+__device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) {
+    const uint32_t l = threadIdx.x;
+    fp r1 = fp_mul(fp_select(l == 0, p.x, p.y), fp_select(l == 0, p.x, fp_select(l == 1, p.y, p.z)));      // X^2 | Y^2 | Y Z
+    fp A = fp_bcast(r1, 0), B = fp_bcast(r1, 1), YZ = fp_bcast(r1, 2);
+    fp E = fp_carry(fp_add_nc(fp_dbl_nc(A), A));
+    fp r2 = fp_sqr(fp_select(l == 0, B, fp_select(l == 1, fp_add(p.x, B), E)));                             // B^2 | (X+B)^2 | E^2
+    fp C = fp_bcast(r2, 0), t = fp_bcast(r2, 1), Fq = fp_bcast(r2, 2);
+    fp D = fp_carry(fp_dbl_nc(fp_sub_nc(fp_sub_nc(t, A), C)));
+    g1_jac r;
+    r.x = fp_reduce(fp_sub_nc(Fq, fp_dbl_nc(D)));
+    fp C8 = fp_dbl_nc(fp_carry(fp_dbl_nc(fp_dbl_nc(C))));
+    r.y = fp_carry(fp_sub_nc(fp_mul(E, fp_sub_nc(D, r.x)), C8));
+    r.z = fp_carry(fp_dbl_nc(YZ));
+    return r;
+}
 // one wave per window: R_w = sum of its nsplit partial sums, then 2^(off_w) * R_w
 __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, msm_win W, uint32_t* __restrict__ winout) {
     uint32_t w = blockIdx.x;
@@ -876,11 +900,11 @@ __global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict_
         g1_jac o = shfl_down_struct(acc, d);
         acc = jac_add_body(acc, o);
     }
-    if (threadIdx.x == 0) {
-        uint32_t sh = msm_win_off(W, w);
-        for (uint32_t i = 0; i < sh; i++) acc = jac_dbl(acc);
-        st_g1_int(winout + (size_t)w * G1W, acc);
-    }
+    acc = g1_jac{fp_bcast(acc.x, 0), fp_bcast(acc.y, 0), fp_bcast(acc.z, 0)};
+    uint32_t sh = msm_win_off(W, w);
+#pragma clang loop unroll(disable)
+    for (uint32_t i = 0; i < sh; i++) acc = g1_dbl_coop(acc);
+    if (threadIdx.x == 0) st_g1_int(winout + (size_t)w * G1W, acc);
 }
 
 // ------------------------------------------------------------------------------------------
