@@ -57,6 +57,93 @@ BLS_HDN void hash_to_field_fp2x2(fp2& u0, fp2& u1, const uint8_t* msg, uint32_t 
     u1.c1 = fp_from_be_words16(uni + 48);
 }
 
+// expand_message_xmd for 32-byte messages (every SignatureSet message, bls_batch_verifier.nim:42) with everything
+// that does not depend on the message folded into constants per DST, built once on the host:
+//   b_0 = H(Z_pad(64) | msg(32) | 0x0100 | 0x00 | DST | len):  state after Z_pad, block 2 = msg | tail[0..32), block 3
+//   b_i = H((b_0 ^ b_(i-1))(32) | i | DST | len):              block 1 = x | tail_i[0..32), block 2 (the same for all i)
+// 18 compressions per message and no byte-wise buffering.  Valid for 28 <= dst_len <= 83 (the tails then span exactly
+// the block boundaries used here); other lengths take hash_to_field_fp2x2.
+struct xmd32_consts {
+    uint32_t h_zpad[8], b0_w8[8], b0_blk3[16], bi_w8[8][8], bi_blk2[16];
+    uint32_t valid;
+};
+inline void xmd32_pack(uint32_t* w, const uint8_t* bytes, int nwords) {
+    for (int i = 0; i < nwords; i++)
+        w[i] = ((uint32_t)bytes[4 * i] << 24) | ((uint32_t)bytes[4 * i + 1] << 16) | ((uint32_t)bytes[4 * i + 2] << 8) | bytes[4 * i + 3];
+}
+inline xmd32_consts xmd32_precompute(const uint8_t* dst, uint32_t dst_len) {
+    xmd32_consts c{};
+    c.valid = dst_len >= 28 && dst_len <= 83;
+    if (!c.valid) return c;
+    uint8_t blk[192];
+    uint32_t w[16];
+    sha256_init(c.h_zpad);
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    sha256_compress_core(c.h_zpad, w);                                   // Z_pad: 64 zero bytes
+    // b_0: tail = 0x01 0x00 | 0x00 | DST | len, message length 64 + 32 + dst_len + 4 bytes
+    for (int i = 0; i < 192; i++) blk[i] = 0;
+    uint32_t t0 = dst_len + 4, tot0 = 96 + t0;
+    blk[0] = 1;
+    for (uint32_t i = 0; i < dst_len; i++) blk[3 + i] = dst[i];
+    blk[3 + dst_len] = (uint8_t)dst_len;
+    blk[t0] = 0x80;
+    xmd32_pack(c.b0_w8, blk, 8);
+    xmd32_pack(c.b0_blk3, blk + 32, 16);
+    c.b0_blk3[15] = tot0 * 8;
+    // b_i: tail_i = i | DST | len, message length 32 + dst_len + 2 bytes
+    uint32_t t1 = dst_len + 2, tot1 = 32 + t1;
+    for (int k = 0; k < 8; k++) {
+        for (int i = 0; i < 192; i++) blk[i] = 0;
+        blk[0] = (uint8_t)(k + 1);
+        for (uint32_t i = 0; i < dst_len; i++) blk[1 + i] = dst[i];
+        blk[1 + dst_len] = (uint8_t)dst_len;
+        blk[t1] = 0x80;
+        xmd32_pack(c.bi_w8[k], blk, 8);
+        if (k == 0) {
+            xmd32_pack(c.bi_blk2, blk + 32, 16);
+            c.bi_blk2[15] = tot1 * 8;
+        }
+    }
+    return c;
+}
+BLS_HD void hash_to_field_fp2x2_msg32(fp2& u0, fp2& u1, const uint32_t (&msg_be)[8], const xmd32_consts& c) {
+    uint32_t b0[8], bi[8], w[16], uni[64];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        b0[i] = c.h_zpad[i];
+        w[i] = msg_be[i];
+        w[8 + i] = c.b0_w8[i];
+    }
+    sha256_compress(b0, w);
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = c.b0_blk3[i];
+    sha256_compress(b0, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) bi[i] = 0;
+    for (int k = 0; k < 8; k++) {
+        uint32_t h[8];
+        sha256_init(h);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            w[i] = b0[i] ^ bi[i];                                        // i = 1: b_0 alone (bi starts as zero)
+            w[8 + i] = c.bi_w8[k][i];
+        }
+        sha256_compress(h, w);
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = c.bi_blk2[i];
+        sha256_compress(h, w);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            bi[i] = h[i];
+            uni[k * 8 + i] = h[i];
+        }
+    }
+    u0.c0 = fp_from_be_words16(uni);
+    u0.c1 = fp_from_be_words16(uni + 16);
+    u1.c0 = fp_from_be_words16(uni + 32);
+    u1.c1 = fp_from_be_words16(uni + 48);
+}
+
 // (is_square(N/D), y) with y = sqrt(N/D) if square, else sqrt(Z * N/D); Z = -(2+u), norm(Z) = 5.
 // Two Fp exponentiations; the first also yields 1/norm(D).
 BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {

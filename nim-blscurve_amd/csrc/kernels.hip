@@ -230,21 +230,29 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, uint4* __restrict__ M, size_t mstride) {
+__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
+                                                         size_t mstride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
     if (i >= n) return;
-    uint8_t msg[32];
     const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t w = mw[j];
-        msg[4 * j] = (uint8_t)w;
-        msg[4 * j + 1] = (uint8_t)(w >> 8);
-        msg[4 * j + 2] = (uint8_t)(w >> 16);
-        msg[4 * j + 3] = (uint8_t)(w >> 24);
-    }
     fp2 u0, u1;
-    hash_to_field_fp2x2(u0, u1, msg, 32, dst.b, dst.len);
+    if (xc.valid) {                                   // wave-uniform: constants of this DST prepared on the host
+        uint32_t mbe[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) mbe[j] = bswap32(mw[j]);
+        hash_to_field_fp2x2_msg32(u0, u1, mbe, xc);
+    } else {
+        uint8_t msg[32];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t w = mw[j];
+            msg[4 * j] = (uint8_t)w;
+            msg[4 * j + 1] = (uint8_t)(w >> 8);
+            msg[4 * j + 2] = (uint8_t)(w >> 16);
+            msg[4 * j + 3] = (uint8_t)(w >> 24);
+        }
+        hash_to_field_fp2x2(u0, u1, msg, 32, dst.b, dst.len);
+    }
     fp2 u = fp2_select((t & 1) != 0, u1, u0);
     soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
 }
@@ -1221,6 +1229,7 @@ struct mi355_bls_ctx {
     bool have_gt = false;
     float timings[8] = {};
     dst_t dst;
+    xmd32_consts xmd;                // message-independent SHA-256 words of expand_message_xmd for this DST
     msm_ws* msm = nullptr;           // lazily sized MSM workspace
 };
 
@@ -1271,6 +1280,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     std::memset(&c->dst, 0, sizeof(c->dst));
     c->dst.len = sizeof(DST_SIG) - 1;
     std::memcpy(c->dst.b, DST_SIG, c->dst.len);
+    c->xmd = xmd32_precompute(c->dst.b, c->dst.len);
     size_t nwaves = c->stride / 64;
 #define ALLOC(p, bytes)                                   \
     do {                                                  \
@@ -1354,7 +1364,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, serial, c->d_r);
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->d_M, c->mstride);
+    k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
     k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));

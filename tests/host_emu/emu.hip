@@ -22,6 +22,15 @@ void emu_sha256(const uint8_t* m, uint32_t n, uint8_t* out) {
 void emu_hash_to_field(const uint8_t* m, uint32_t n, const uint8_t* dst, uint32_t dn, uint8_t* out192) {
     fp2 u0, u1; hash_to_field_fp2x2(u0, u1, m, n, dst, dn); fp2_store_le(out192, u0); fp2_store_le(out192 + 96, u1);
 }
+// the 32-byte-message fast path of k_hash_map (constants per DST + 18 compressions); returns 0 when the DST length is outside its range
+int emu_hash_to_field_msg32(const uint8_t* m32, const uint8_t* dst, uint32_t dn, uint8_t* out192) {
+    xmd32_consts c = xmd32_precompute(dst, dn);
+    if (!c.valid) return 0;
+    uint32_t mbe[8];
+    xmd32_pack(mbe, m32, 8);
+    fp2 u0, u1; hash_to_field_fp2x2_msg32(u0, u1, mbe, c); fp2_store_le(out192, u0); fp2_store_le(out192 + 96, u1);
+    return 1;
+}
 // u (96 B) -> Jacobian point on E2' (288 B)
 void emu_sswu(const uint8_t* u, uint8_t* out) { g2_jac_store(out, sswu_g2(fp2_load_le(u))); }
 void emu_iso3(const uint8_t* in, uint8_t* out) { g2_jac_store(out, iso3_g2(g2_jac_load(in))); }

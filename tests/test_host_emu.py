@@ -55,6 +55,23 @@ def test_hash_to_g2_stages(emu):
         assert o.g2_compress(ha).hex() == v["h_compressed"]
 
 
+def test_hash_to_field_fast_path_for_32_byte_messages(emu):
+    """k_hash_map's specialised expand_message_xmd (message-independent words precomputed per DST) against the
+    generic byte-wise one and the oracle, for several DST lengths incl. the edges of its range."""
+    rng = random.Random(5)
+    for dst in [o.DST_SIG, b"BLS_POP_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_", b"x" * 28, b"y" * 83, b"QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_"]:
+        for _ in range(3):
+            msg = bytes(rng.getrandbits(8) for _ in range(32))
+            a, b = buf(192), buf(192)
+            assert emu.emu_hash_to_field_msg32(msg, dst, len(dst), a) == 1
+            emu.emu_hash_to_field(msg, 32, dst, len(dst), b)
+            assert a.raw == b.raw
+            u = o.hash_to_field_fp2(msg, dst, 2)
+            assert a.raw == b"".join(o.fp_to_mont_bytes(c) for c in (u[0][0], u[0][1], u[1][0], u[1][1]))
+    out = buf(192)
+    assert emu.emu_hash_to_field_msg32(bytes(32), b"z" * 27, 27, out) == 0 and emu.emu_hash_to_field_msg32(bytes(32), b"z" * 84, 84, out) == 0
+
+
 def test_scalar_mul_and_add(emu):
     rng = random.Random(5)
     p = o.g1_mul(o.G1_GEN, rng.randrange(o.R))
