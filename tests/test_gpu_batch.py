@@ -147,7 +147,7 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
     assert co.batch_verify(bytes(bad), rnd, nt) is False
 
 
-@pytest.mark.parametrize("n", [2048, 40960])
+@pytest.mark.parametrize("n", [1024, 2048, 39999, 40000, 40960])
 def test_bucket_fold_of_the_signature_side(m, n):
     """n >= 1024: the signatures are folded into digit buckets that become extra Miller pairs (4-bit digits below
     40 000 tuples, 8-bit from there).  sum [r_i]S_i (folded from the buckets on demand) and the final GT value must
