@@ -61,6 +61,18 @@ int mi355_bls_batch_verify_serial(mi355_bls_ctx* ctx, const void* sets, size_t n
  * work enqueued on `stream` (hipStream_t, may be NULL); synchronises the stream before returning. */
 int mi355_bls_batch_verify_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream);
 
+/* Asynchronous form of mi355_bls_batch_verify_device, for a caller that keeps several batches in flight from ONE host
+ * thread (one context + one stream per batch in flight, cf. "one cache per concurrent caller",
+ * bls_batch_verifier.nim:389-391): submit enqueues the whole verification on `stream` and returns at once (0, or a
+ * negative error; n == 0 is an error here); wait blocks until that batch is done and returns its verdict (1 / 0) exactly
+ * as mi355_bls_batch_verify_device would.  One batch per context at a time; d_sets must stay valid until wait returns;
+ * rnd is consumed at submit.  `after` (optional): another context whose batch was submitted earlier; this batch then
+ * starts when the whole-chip kernels of that batch are done, i.e. it runs beside that batch's serial tail (a few waves:
+ * step products, Horner, final exponentiation) - deterministic software pipelining with two or three contexts. */
+int mi355_bls_batch_submit_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream,
+                                  mi355_bls_ctx* after);
+int mi355_bls_batch_wait(mi355_bls_ctx* ctx);
+
 /* Multi-GPU sharding (replaces processSingleChunk + merge, bls_batch_verifier.nim:326-369).
  * The global batch of n_total sets is cut into B = min(n_total, num_threads) chunks by
  * parallel_chunks (parallel_chunks.nim:42-66); this call processes chunks [chunk_lo, chunk_hi),

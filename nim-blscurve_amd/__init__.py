@@ -51,6 +51,8 @@ def lib():
         L.mi355_bls_batch_verify.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_batch_verify_serial.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_batch_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp]
+        L.mi355_bls_batch_submit_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp, vp]
+        L.mi355_bls_batch_wait.argtypes = [vp]
         L.mi355_bls_batch_shard_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, ctypes.c_char_p, ctypes.POINTER(i32)]
         L.mi355_bls_finalverify_shards.argtypes = [vp, ctypes.c_char_p, sz]
         L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
@@ -160,6 +162,14 @@ class BatchedBLSVerifierCache:
     # -- device-resident entry points --
     def verify_device(self, d_ptr, n, secureRandomBytes, stream=0):
         return bool(_check(lib().mi355_bls_batch_verify_device(self._h, d_ptr, n, bytes(secureRandomBytes), stream)))
+
+    def submit_device(self, d_ptr, n, secureRandomBytes, stream=0, after=None):
+        """Enqueue a batch verification and return at once; wait() gives its verdict.  after: a context whose
+        batch was submitted before; this one then starts beside that batch's serial tail."""
+        _check(lib().mi355_bls_batch_submit_device(self._h, d_ptr, n, bytes(secureRandomBytes), stream, after._h if after is not None else None))
+
+    def wait(self):
+        return bool(_check(lib().mi355_bls_batch_wait(self._h)))
 
     def shard_device(self, d_ptr, n_total, chunk_lo, chunk_hi, secureRandomBytes, stream=0):
         out = ctypes.create_string_buffer(576)

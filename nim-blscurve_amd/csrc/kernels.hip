@@ -1218,6 +1218,10 @@ struct mi355_bls_ctx {
     uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
     uint32_t* d_gt = nullptr;
     uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
+    uint32_t* h_flags = nullptr;     // pinned host copy of d_flags[0..1] (asynchronous submit / wait)
+    bool pending = false;            // a submitted batch has not been waited for yet
+    bool wide_recorded = false;      // ev_lp (end of the whole-chip kernels) has been recorded at least once
+    hipStream_t pending_stream = nullptr;
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
     hipEvent_t ev_side = nullptr;
@@ -1247,6 +1251,7 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
@@ -1314,6 +1319,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_flags, 16);
+    HIPCHK(hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault));      // [0..3] flags, bytes 16..47: staging copy of rnd
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
@@ -1357,7 +1363,8 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
                      size_t tuple_base, size_t n, int serial, const uint8_t rnd[32], hipStream_t st) {
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->d_rnd, rnd, 32, hipMemcpyHostToDevice, st));
+    std::memcpy(c->h_flags + 4, rnd, 32);                      // pinned staging: the copy below is then truly asynchronous
+    HIPCHK(hipMemcpyAsync(c->d_rnd, c->h_flags + 4, 32, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
     uint32_t n32 = (uint32_t)n;
     uint32_t nb = (n32 + WAVE - 1) / WAVE;
@@ -1446,6 +1453,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         HIPCHK(hipEventRecord(c->ev_lp, st));
         k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk * WAVE, c->d_lines, c->stride, xpair, c->d_L);
     }
+    c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
     k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1);
     HIPCHK(hipEventRecord(c->ev[7], st));
@@ -1469,27 +1477,56 @@ static int collect_timings(mi355_bls_ctx* c, int last_ev) {
     return 0;
 }
 
-static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
+// Enqueue a whole batch verification (nothing is waited for); the verdict lands in the context's pinned host words.
+static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
     if (!c || !rnd) return MI355_BLS_ERR_ARG;
-    if (n == 0) return 0;                      // bls_batch_verifier.nim:137-139, :312-314
-    if (!d_sets) return MI355_BLS_ERR_ARG;
+    if (!d_sets || n == 0) return MI355_BLS_ERR_ARG;
+    if (c->pending) {
+        g_err = "a batch submitted on this context has not been waited for";
+        return MI355_BLS_ERR_ARG;
+    }
     uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
     int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
     if (rc) return rc;
     k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1);
     HIPCHK(hipEventRecord(c->ev[8], st));
-    uint32_t fl[2];
-    HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 8, hipMemcpyDeviceToHost, st));
+    c->pending = true;
+    c->pending_stream = st;
+    return 0;
+}
+static int verify_wait(mi355_bls_ctx* c) {
+    if (!c || !c->pending) return MI355_BLS_ERR_ARG;
+    c->pending = false;
+    HIPCHK(hipStreamSynchronize(c->pending_stream));
     c->have_gt = true;
     float fin = 0;
-    rc = collect_timings(c, 7);
+    int rc = collect_timings(c, 7);
     if (rc) return rc;
     HIPCHK(hipEventElapsedTime(&fin, c->ev[7], c->ev[8]));
     c->timings[6] += fin;
     c->timings[7] += fin;
-    return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
+    return (c->h_flags[0] == 0 && c->h_flags[1] == 1) ? 1 : 0;
 }
+static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
+    if (!c || !rnd) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                      // bls_batch_verifier.nim:137-139, :312-314
+    int rc = verify_enqueue(c, d_sets, n, rnd, serial, st);
+    if (rc) return rc;
+    return verify_wait(c);
+}
+
+extern "C" int mi355_bls_batch_submit_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream, mi355_bls_ctx* after) {
+    if (after && after != c && after->wide_recorded) {
+        // software pipelining: this batch starts when `after`'s batch has finished hashing, so the batches in flight sit
+        // at different stages and the serial tail of one always runs beside whole-chip kernels of another (batches that
+        // start together stay in phase: their tails coincide and leave the chip idle)
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, after->ev[2], 0));
+    }
+    return verify_enqueue(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);
+}
+extern "C" int mi355_bls_batch_wait(mi355_bls_ctx* c) { return verify_wait(c); }
 
 extern "C" int mi355_bls_batch_verify_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream) {
     return verify_common(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);

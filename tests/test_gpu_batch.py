@@ -147,6 +147,39 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
     assert co.batch_verify(bytes(bad), rnd, nt) is False
 
 
+def test_submit_wait(m):
+    """Asynchronous entry points: several contexts kept in flight from one host thread give the verdicts of the
+    blocking call; a context takes one batch at a time."""
+    import torch
+    c = [x for x in _cases() if x["name"] == "n17"][0]
+    rec, rnd = bytes.fromhex(c["sets"]), bytes.fromhex(c["rnd"])
+    n = 17
+    bad = bytearray(rec)
+    bad[320 * 5 + 100] ^= 1
+    d_ok = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=4) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    plan = [d_ok, d_bad, d_ok, d_ok, d_bad, d_bad, d_ok]
+    got, busy = [], [None] * 3
+    for i, d in enumerate(plan):
+        s = i % 3
+        if busy[s] is not None:
+            got.append((busy[s], caches[s].wait()))
+        caches[s].submit_device(d.data_ptr(), n, rnd, streams[s].cuda_stream, after=caches[(s - 1) % 3] if i % 2 else None)
+        busy[s] = i
+    with pytest.raises(m.BlsGpuError):
+        caches[0].submit_device(d_ok.data_ptr(), n, rnd, streams[0].cuda_stream)      # still pending
+    for j in range(3):
+        s = (len(plan) + j) % 3
+        got.append((busy[s], caches[s].wait()))
+    assert dict(got) == {i: (d is d_ok) for i, d in enumerate(plan)}
+    with pytest.raises(m.BlsGpuError):
+        caches[0].wait()                                                              # nothing pending
+    assert caches[0].verify_device(d_ok.data_ptr(), n, rnd) is True
+
+
 @pytest.mark.parametrize("n", [1024, 2048, 39999, 40000, 40960])
 def test_bucket_fold_of_the_signature_side(m, n):
     """n >= 1024: the signatures are folded into digit buckets that become extra Miller pairs (4-bit digits below
