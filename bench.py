@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=65536, help="tuples per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="tuples in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--threads", action="store_true", help="single GPU: one blocking call per host thread instead of submit / wait from one thread")
+    ap.add_argument("--threads", action="store_true", help="one blocking call per host thread instead of submit / wait from one thread")
     ap.add_argument("--inflight", type=int, default=3, help="batches kept in flight per GPU (independent caller contexts)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the fastAggregateVerify / MSM side measurements")
@@ -126,18 +126,27 @@ def main():
             free.put(slot)
 
     def run_steps_async(k, record):
-        """Single GPU: one host thread keeps `inflight` batches in flight with the submit / wait entry points
-        (context i % inflight; a context is waited for right before it is reused, i.e. oldest first).  Every batch is
+        """One host thread keeps `inflight` batches in flight with the submit / wait entry points (context
+        i % inflight; a context is waited for right before it is reused, i.e. oldest first).  Every batch is
         chained to the one submitted before it (`after`): it starts when that one has finished hashing, so the batches
-        in flight sit at different stages and a serial tail always runs beside whole-chip kernels of another batch."""
+        in flight sit at different stages and a serial tail always runs beside whole-chip kernels of another batch.
+        N > 1: the per-step all_gather + final exponentiation (rank 0) happen in step order as results arrive."""
         ok = True
         busy = [False] * inflight
 
         def collect(slot):
-            res = caches[slot].wait()
+            c = caches[slot]
             busy[slot] = False
+            if world == 1:
+                res = c.wait()
+            else:
+                state, okf = c.shard_wait()
+                blobs = all_gather(state + bytes([1 if okf else 0]) + bytes(7))
+                res = True
+                if rank == 0:
+                    res = all(b[576] == 1 for b in blobs) and fv_cache.finalverify_shards([b[:576] for b in blobs])
             if record:
-                for kk, v in list(caches[slot].timings().items()) + list(caches[slot].kernel_timings().items()):
+                for kk, v in list(c.timings().items()) + list(c.kernel_timings().items()):
                     stage_acc[kk] = stage_acc.get(kk, 0.0) + v
             return res
 
@@ -146,7 +155,11 @@ def main():
             slot = it % inflight
             if busy[slot]:
                 ok = collect(slot) and ok
-            caches[slot].submit_device(d_sets.data_ptr(), n, r, streams[slot].cuda_stream, after=caches[(slot - 1) % inflight] if inflight > 1 else None)
+            after = caches[(slot - 1) % inflight] if inflight > 1 else None
+            if world == 1:
+                caches[slot].submit_device(d_sets.data_ptr(), n, r, streams[slot].cuda_stream, after=after)
+            else:
+                caches[slot].shard_submit_device(d_sets.data_ptr(), n_total, lo, hi, r, streams[slot].cuda_stream, after=after)
             busy[slot] = True
         for j in range(inflight):
             slot = (k + j) % inflight
@@ -156,7 +169,7 @@ def main():
 
     def run_steps(k, record):
         """k steps; the collective and the verdict of every step are issued in step order on this thread."""
-        if world == 1 and not a.threads:
+        if not a.threads:
             return run_steps_async(k, record)
         ok = True
         with ThreadPoolExecutor(max_workers=inflight) as pool:

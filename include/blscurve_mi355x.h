@@ -83,6 +83,10 @@ int mi355_bls_batch_wait(mi355_bls_ctx* ctx);
  * (blst_pairing_merge, blst_abi.nim:508). */
 int mi355_bls_batch_shard_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
                                  const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok);
+/* asynchronous form (see mi355_bls_batch_submit_device / mi355_bls_batch_wait) */
+int mi355_bls_batch_shard_submit_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
+                                        const uint8_t rnd[32], void* stream, mi355_bls_ctx* after);
+int mi355_bls_batch_shard_wait(mi355_bls_ctx* ctx, uint8_t out_fp12[576], int* out_ok);
 
 /* merge + finalVerify (blst_min_pubkey_sig_core.nim:657-672): product of k shard states (host
  * memory, k x 576 B), one final exponentiation on the device, == 1. */

@@ -54,6 +54,8 @@ def lib():
         L.mi355_bls_batch_submit_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp, vp]
         L.mi355_bls_batch_wait.argtypes = [vp]
         L.mi355_bls_batch_shard_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, ctypes.c_char_p, ctypes.POINTER(i32)]
+        L.mi355_bls_batch_shard_submit_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, vp]
+        L.mi355_bls_batch_shard_wait.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
         L.mi355_bls_finalverify_shards.argtypes = [vp, ctypes.c_char_p, sz]
         L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mi355_bls_chunk_range.restype = None
@@ -175,6 +177,16 @@ class BatchedBLSVerifierCache:
         out = ctypes.create_string_buffer(576)
         ok = ctypes.c_int()
         _check(lib().mi355_bls_batch_shard_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, bytes(secureRandomBytes), stream, out, ctypes.byref(ok)))
+        return out.raw, bool(ok.value)
+
+    def shard_submit_device(self, d_ptr, n_total, chunk_lo, chunk_hi, secureRandomBytes, stream=0, after=None):
+        _check(lib().mi355_bls_batch_shard_submit_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, bytes(secureRandomBytes), stream,
+                                                         after._h if after is not None else None))
+
+    def shard_wait(self):
+        out = ctypes.create_string_buffer(576)
+        ok = ctypes.c_int()
+        _check(lib().mi355_bls_batch_shard_wait(self._h, out, ctypes.byref(ok)))
         return out.raw, bool(ok.value)
 
     def finalverify_shards(self, states):

@@ -1319,7 +1319,7 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_flags, 16);
-    HIPCHK(hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault));      // [0..3] flags, bytes 16..47: staging copy of rnd
+    HIPCHK(hipHostMalloc((void**)&c->h_flags, 1024, hipHostMallocDefault));    // words 0..3 flags, 4..11 staging copy of rnd, 16..159 shard state
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
@@ -1545,24 +1545,50 @@ static int verify_host(mi355_bls_ctx* c, const void* sets, size_t n, const uint8
 extern "C" int mi355_bls_batch_verify(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 0); }
 extern "C" int mi355_bls_batch_verify_serial(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 1); }
 
-extern "C" int mi355_bls_batch_shard_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
-                                            const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok) {
-    if (!c || !rnd || !out_fp12 || !out_ok || n_total == 0) return MI355_BLS_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
+static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi, const uint8_t rnd[32],
+                         hipStream_t st, mi355_bls_ctx* after) {
+    if (!c || !rnd || n_total == 0 || !d_sets) return MI355_BLS_ERR_ARG;
+    if (c->pending) {
+        g_err = "a batch submitted on this context has not been waited for";
+        return MI355_BLS_ERR_ARG;
+    }
     uint32_t B = (uint32_t)(n_total < c->num_threads ? n_total : c->num_threads);
     if (chunk_hi > B) chunk_hi = B;
     if (chunk_lo >= chunk_hi) return MI355_BLS_ERR_ARG;
     size_t first, count;
     mi355_bls_chunk_range(n_total, c->num_threads, chunk_lo, chunk_hi, &first, &count);
+    if (after && after != c && after->wide_recorded) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamWaitEvent(st, after->ev[2], 0));          // see mi355_bls_batch_submit_device
+    }
     int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
     if (rc) return rc;
-    uint32_t fl = 0;
-    HIPCHK(hipMemcpyAsync(out_fp12, c->d_states, 576, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&fl, c->d_flags, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *out_ok = fl == 0 ? 1 : 0;
+    HIPCHK(hipMemcpyAsync(c->h_flags + 16, c->d_states, 576, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4, hipMemcpyDeviceToHost, st));
+    c->pending = true;
+    c->pending_stream = st;
+    return 0;
+}
+static int shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) {
+    if (!c || !out_fp12 || !out_ok || !c->pending) return MI355_BLS_ERR_ARG;
+    c->pending = false;
+    HIPCHK(hipStreamSynchronize(c->pending_stream));
+    std::memcpy(out_fp12, c->h_flags + 16, 576);
+    *out_ok = c->h_flags[0] == 0 ? 1 : 0;
     return collect_timings(c, 7);
 }
+extern "C" int mi355_bls_batch_shard_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
+                                            const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok) {
+    if (!out_fp12 || !out_ok) return MI355_BLS_ERR_ARG;
+    int rc = shard_enqueue(c, d_sets, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, nullptr);
+    if (rc) return rc;
+    return shard_wait(c, out_fp12, out_ok);
+}
+extern "C" int mi355_bls_batch_shard_submit_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
+                                                   const uint8_t rnd[32], void* stream, mi355_bls_ctx* after) {
+    return shard_enqueue(c, d_sets, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, after);
+}
+extern "C" int mi355_bls_batch_shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) { return shard_wait(c, out_fp12, out_ok); }
 
 extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp12s, size_t kk) {
     if (!c || !fp12s || kk == 0 || kk > 64) return MI355_BLS_ERR_ARG;
