@@ -67,8 +67,9 @@ int mi355_bls_batch_verify_device(mi355_bls_ctx* ctx, const void* d_sets, size_t
  * negative error; n == 0 is an error here); wait blocks until that batch is done and returns its verdict (1 / 0) exactly
  * as mi355_bls_batch_verify_device would.  One batch per context at a time; d_sets must stay valid until wait returns;
  * rnd is consumed at submit.  `after` (optional): another context whose batch was submitted earlier; this batch then
- * starts when the whole-chip kernels of that batch are done, i.e. it runs beside that batch's serial tail (a few waves:
- * step products, Horner, final exponentiation) - deterministic software pipelining with two or three contexts. */
+ * starts when that batch has finished hashing and multiplying its public keys, so the batches in flight sit at different
+ * stages and the serial tail of one (a few waves: step products, Horner, final exponentiation) always runs beside
+ * whole-chip kernels of another - deterministic software pipelining; three contexts are enough. */
 int mi355_bls_batch_submit_device(mi355_bls_ctx* ctx, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream,
                                   mi355_bls_ctx* after);
 int mi355_bls_batch_wait(mi355_bls_ctx* ctx);

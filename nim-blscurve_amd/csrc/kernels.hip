@@ -1518,11 +1518,12 @@ static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, cons
 
 extern "C" int mi355_bls_batch_submit_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream, mi355_bls_ctx* after) {
     if (after && after != c && after->wide_recorded) {
-        // software pipelining: this batch starts when `after`'s batch has finished hashing, so the batches in flight sit
+        // software pipelining: this batch starts when `after`'s batch has finished hashing and its public-key multiplications (the best of the
+        // stage boundaries tried: 13.3 ms per batch against 13.7 one stage earlier and 17 one later), so the batches in flight sit
         // at different stages and the serial tail of one always runs beside whole-chip kernels of another (batches that
         // start together stay in phase: their tails coincide and leave the chip idle)
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, after->ev[2], 0));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, after->ev[3], 0));
     }
     return verify_enqueue(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);
 }
@@ -1559,7 +1560,7 @@ static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, u
     mi355_bls_chunk_range(n_total, c->num_threads, chunk_lo, chunk_hi, &first, &count);
     if (after && after != c && after->wide_recorded) {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamWaitEvent(st, after->ev[2], 0));          // see mi355_bls_batch_submit_device
+        HIPCHK(hipStreamWaitEvent(st, after->ev[3], 0));          // see mi355_bls_batch_submit_device
     }
     int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
     if (rc) return rc;
