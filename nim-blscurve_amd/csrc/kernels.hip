@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
 }
 
 // per step: product of the nblk range partials, times the line of the extra pair `xpair`
-// (the aggregated-signature pair, whose 68 lines are computed by a side-stream wave meanwhile)
+// (small batches: the aggregated-signature pair)
 __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__ part, uint32_t nblk, const uint4* __restrict__ lines, size_t stride,
                                                     uint32_t xpair, uint32_t* __restrict__ L) {
     uint32_t s = blockIdx.x;
@@ -1224,10 +1224,8 @@ struct mi355_bls_ctx {
     hipStream_t pending_stream = nullptr;
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
-    hipEvent_t ev_side = nullptr;
     hipEvent_t ev_hm = nullptr, ev_lp = nullptr;   // inside the hash stage (after k_hash_map) and the line-product stage (after k_lineprod)
     float ktimes[4] = {};         // k_hash_map, k_hash_clear, k_lineprod, k_lineprod2 of the last batch call
-    hipStream_t side = nullptr;   // one-wave side work that runs beside a main-stream kernel
     uint32_t slots = 1024;        // wave slots at one wave per SIMD: 4 x CUs
     size_t last_n = 0;
     bool have_gt = false;
@@ -1254,12 +1252,10 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->ev_hm) (void)hipEventDestroy(c->ev_hm);
     if (c->ev_lp) (void)hipEventDestroy(c->ev_lp);
     if (c->ev_deser0) (void)hipEventDestroy(c->ev_deser0);
     if (c->ev_deser1) (void)hipEventDestroy(c->ev_deser1);
-    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->msm) {
         msm_free(c->msm);
         delete c->msm;
@@ -1323,7 +1319,6 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_hm));
     HIPCHK(hipEventCreate(&c->ev_lp));
     HIPCHK(hipEventCreate(&c->ev_deser0));
@@ -1414,34 +1409,15 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
             k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
         }
         HIPCHK(hipEventRecord(c->ev[4], st));
-        // The extra (AggrSign, -G1) pair goes through k_lineprod2; when it would cost the k_lines launch one
-        // more round of waves, its 68 lines are produced by one side-stream wave that runs beside k_lineprod
-        // (which is then sized to leave a few slots free).
-        uint32_t nb1 = (n32 + 1 + WAVE - 1) / WAVE;
-        bool use_side = (nb1 + c->slots - 1) / c->slots > (nb + c->slots - 1) / c->slots;
-        if (use_side) {
-            k_lines<<<nb, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32, c->stride, c->d_lines);
-            HIPCHK(hipEventRecord(c->ev[5], st));
-            // created on first use: a stream takes a share of a hardware queue, and callers that keep several
-            // contexts in flight want those for their own streams
-            if (!c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-            HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
-            k_lines<<<1, WAVE, 0, c->side>>>(c->d_P, c->d_H, n32, 1, c->stride, c->d_lines);
-            HIPCHK(hipEventRecord(c->ev_side, c->side));
-            // workgroups are dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first one:
-            // leave one free wave slot per XCD so the side-stream wave really runs beside k_lineprod
-            nblk_max = (c->slots > 8 ? c->slots - 8 : c->slots) / N_LINES;
-        } else {
-            k_lines<<<nb1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
-            HIPCHK(hipEventRecord(c->ev[5], st));
-        }
+        // small batch: the one extra (AggrSign, -G1) pair is pair n; its lines are folded in by k_lineprod2
+        k_lines<<<(n32 + 1 + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, n32 + 1, c->stride, c->d_lines);
+        HIPCHK(hipEventRecord(c->ev[5], st));
         uint32_t nblk0 = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
         uint32_t m0 = (n32 + WAVE * nblk0 - 1) / (WAVE * nblk0);
         if (m0 < 1) m0 = 1;
         nblk0 = (n32 + WAVE * m0 - 1) / (WAVE * m0);
         k_lineprod<<<dim3(N_LINES, nblk0), WAVE, 0, st>>>(c->d_lines, n32, c->stride, m0, c->d_lpart, nblk0, 0);
         HIPCHK(hipEventRecord(c->ev_lp, st));
-        if (use_side) HIPCHK(hipStreamWaitEvent(st, c->ev_side, 0));
         k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk0, c->d_lines, c->stride, xpair, c->d_L);
     }
     if (xpair == 0xffffffffu) {
