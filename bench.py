@@ -37,8 +37,8 @@ KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=65536, help="tuples per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="tuples in the CPU baseline sample (0 = auto)")
     ap.add_argument("--threads", action="store_true", help="one blocking call per host thread instead of submit / wait from one thread")
