@@ -238,9 +238,9 @@ def main():
             "input_gen_s": round(gen_s, 1),
         }
         out["roofline"]["traffic"] = pmc_traffic(dom)
-        if not a.no_aux:
+        if not a.no_aux and world == 1:
             out["aux"] = aux_rows(m, cache, dev)
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:                # the CPU baseline is timed at N = 1 only
             import c_oracle as co      # the CPU restatement: this leg only
             out["cpu_baseline"] = cpu_baseline(co, a.cpu_sample, bytes(rnd))
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
