@@ -263,11 +263,61 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
     soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
 }
 
-// arbitrary-length message (fastAggregateVerify / coreVerify shape), one lane
-__global__ void k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g2_jac h = hash_to_g2(msg, len, dst.b, dst.len);
-    soa_st_g2(H, stride, slot, h);
+// arbitrary-length message (fastAggregateVerify / coreVerify shape): ONE message, so latency is all that matters.
+// A wave works on it cooperatively: the two SSWU maps run in lanes 0 and 1, and every G2 doubling of the cofactor
+// clearing (128 of them) spreads the independent products of its first two rounds over lanes 0..2
+// (3 multiplication times per doubling instead of 7).  Every lane holds the same points throughout.
+__device__ __forceinline__ fp2 fp2_bcast(const fp2& a, int src) {
+    fp2 r;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        r.c0.l[i] = __shfl(a.c0.l[i], src, WAVE);
+        r.c1.l[i] = __shfl(a.c1.l[i], src, WAVE);
+    }
+    return r;
+}
+__device__ __forceinline__ g2_jac g2_bcast(const g2_jac& a, int src) { return g2_jac{fp2_bcast(a.x, src), fp2_bcast(a.y, src), fp2_bcast(a.z, src)}; }
+// lane-parallel jac_dbl (same formulas, carries and reductions as curve.hpp's)
+__device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p) {
+    const uint32_t l = threadIdx.x;
+    fp2 r1 = fp2_mul(fp2_select(l == 0, p.x, p.y), fp2_select(l == 0, p.x, fp2_select(l == 1, p.y, p.z)));        // X^2 | Y^2 | Y Z
+    fp2 A = fp2_bcast(r1, 0), B = fp2_bcast(r1, 1), YZ = fp2_bcast(r1, 2);
+    fp2 E = fp2_carry(fp2_add_nc(fp2_dbl_nc(A), A));
+    fp2 r2 = fp2_sqr(fp2_select(l == 0, B, fp2_select(l == 1, fp2_add(p.x, B), E)));                               // B^2 | (X+B)^2 | E^2
+    fp2 C = fp2_bcast(r2, 0), t = fp2_bcast(r2, 1), Fq = fp2_bcast(r2, 2);
+    fp2 D = fp2_carry(fp2_dbl_nc(fp2_sub_nc(fp2_sub_nc(t, A), C)));
+    g2_jac r;
+    r.x = fp2_reduce(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
+    fp2 C8 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_dbl_nc(C))));
+    r.y = fp2_carry(fp2_sub_nc(fp2_mul(E, fp2_sub_nc(D, r.x)), C8));
+    r.z = fp2_carry(fp2_dbl_nc(YZ));
+    return r;
+}
+__device__ g2_jac g2_mul_x_coop(const g2_jac& p) {
+    g2_jac acc = jac_inf<fp2>();
+#pragma clang loop unroll(disable)
+    for (int i = 63; i >= 0; i--) {
+        acc = g2_dbl_coop(acc);
+        if ((k::X_ABS >> i) & 1) acc = jac_add(acc, p);
+    }
+    return jac_neg(acc);
+}
+__global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
+    fp2 u0, u1;
+    hash_to_field_fp2x2(u0, u1, msg, len, dst.b, dst.len);
+    g2_jac q = iso3_g2(sswu_g2(fp2_select(threadIdx.x == 1, u1, u0)));          // lane 1 maps u_1, every other lane u_0
+    g2_jac p = jac_add(g2_bcast(q, 0), g2_bcast(q, 1));
+    // clear_cofactor_g2 (h2c.hpp) with the doubling chains lane-parallel
+    g2_jac t1 = g2_mul_x_coop(p);
+    g2_jac t2 = g2_psi(p);
+    g2_jac t3 = g2_psi(g2_psi(g2_dbl_coop(p)));
+    t3 = jac_add(t3, jac_neg(t2));
+    t2 = jac_add(t1, t2);
+    t2 = g2_mul_x_coop(t2);
+    t3 = jac_add(t3, t2);
+    t3 = jac_add(t3, jac_neg(t1));
+    g2_jac h = jac_add(t3, jac_neg(p));
+    if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, h);
 }
 
 __global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
@@ -1686,7 +1736,7 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, st);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_hash_one<<<1, 1, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
+    k_hash_one<<<1, WAVE, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
     k_fav_setup<<<1, 1, 0, st>>>(c->d_agg1, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_lines<<<1, WAVE, 0, st>>>(c->d_P, c->d_H, 0, 2, c->stride, c->d_lines);
