@@ -181,6 +181,25 @@ __device__ __forceinline__ T shfl_down_struct(const T& v, int delta) {
     return r;
 }
 
+// broadcast within a group of lanes: value of lane gbase + role
+__device__ __forceinline__ fp2 fp2_from_role(const fp2& a, uint32_t gbase, uint32_t role) {
+    fp2 r;
+    int src = (int)(gbase + role);
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        r.c0.l[i] = __shfl(a.c0.l[i], src, WAVE);
+        r.c1.l[i] = __shfl(a.c1.l[i], src, WAVE);
+    }
+    return r;
+}
+__device__ __forceinline__ fp fp_from_role(const fp& a, uint32_t gbase, uint32_t role) {
+    fp r;
+    int src = (int)(gbase + role);
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_blind: chunk c of B (parallel_chunks.nim:42-66) -> seed = SHA256(rnd || LE64(c)), then per tuple
 // seed <- SHA256(seed) until low u64 != 0 (blst_min_pubkey_sig_core.nim:497-507,:545-556).
@@ -267,24 +286,14 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
 // A wave works on it cooperatively: the two SSWU maps run in lanes 0 and 1, and every G2 doubling of the cofactor
 // clearing (128 of them) spreads the independent products of its first two rounds over lanes 0..2
 // (3 multiplication times per doubling instead of 7).  Every lane holds the same points throughout.
-__device__ __forceinline__ fp2 fp2_bcast(const fp2& a, int src) {
-    fp2 r;
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) {
-        r.c0.l[i] = __shfl(a.c0.l[i], src, WAVE);
-        r.c1.l[i] = __shfl(a.c1.l[i], src, WAVE);
-    }
-    return r;
-}
-__device__ __forceinline__ g2_jac g2_bcast(const g2_jac& a, int src) { return g2_jac{fp2_bcast(a.x, src), fp2_bcast(a.y, src), fp2_bcast(a.z, src)}; }
-// lane-parallel jac_dbl (same formulas, carries and reductions as curve.hpp's)
-__device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p) {
-    const uint32_t l = threadIdx.x;
-    fp2 r1 = fp2_mul(fp2_select(l == 0, p.x, p.y), fp2_select(l == 0, p.x, fp2_select(l == 1, p.y, p.z)));        // X^2 | Y^2 | Y Z
-    fp2 A = fp2_bcast(r1, 0), B = fp2_bcast(r1, 1), YZ = fp2_bcast(r1, 2);
+// lane-parallel jac_dbl inside a group of 8 lanes that all hold the same point (same formulas, carries and
+// reductions as curve.hpp's): roles 0..2 take the three independent products of each of the first two rounds
+__device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
+    fp2 r1 = fp2_mul(fp2_select(role == 0, p.x, p.y), fp2_select(role == 0, p.x, fp2_select(role == 1, p.y, p.z)));        // X^2 | Y^2 | Y Z
+    fp2 A = fp2_from_role(r1, gbase, 0), B = fp2_from_role(r1, gbase, 1), YZ = fp2_from_role(r1, gbase, 2);
     fp2 E = fp2_carry(fp2_add_nc(fp2_dbl_nc(A), A));
-    fp2 r2 = fp2_sqr(fp2_select(l == 0, B, fp2_select(l == 1, fp2_add(p.x, B), E)));                               // B^2 | (X+B)^2 | E^2
-    fp2 C = fp2_bcast(r2, 0), t = fp2_bcast(r2, 1), Fq = fp2_bcast(r2, 2);
+    fp2 r2 = fp2_sqr(fp2_select(role == 0, B, fp2_select(role == 1, fp2_add(p.x, B), E)));                                 // B^2 | (X+B)^2 | E^2
+    fp2 C = fp2_from_role(r2, gbase, 0), t = fp2_from_role(r2, gbase, 1), Fq = fp2_from_role(r2, gbase, 2);
     fp2 D = fp2_carry(fp2_dbl_nc(fp2_sub_nc(fp2_sub_nc(t, A), C)));
     g2_jac r;
     r.x = fp2_reduce(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
@@ -293,31 +302,49 @@ __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p) {
     r.z = fp2_carry(fp2_dbl_nc(YZ));
     return r;
 }
-__device__ g2_jac g2_mul_x_coop(const g2_jac& p) {
+__device__ g2_jac g2_mul_x_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
     g2_jac acc = jac_inf<fp2>();
 #pragma clang loop unroll(disable)
     for (int i = 63; i >= 0; i--) {
-        acc = g2_dbl_coop(acc);
+        acc = g2_dbl_coop(acc, gbase, role);
         if ((k::X_ABS >> i) & 1) acc = jac_add(acc, p);
     }
     return jac_neg(acc);
 }
-__global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
-    fp2 u0, u1;
-    hash_to_field_fp2x2(u0, u1, msg, len, dst.b, dst.len);
-    g2_jac q = iso3_g2(sswu_g2(fp2_select(threadIdx.x == 1, u1, u0)));          // lane 1 maps u_1, every other lane u_0
-    g2_jac p = jac_add(g2_bcast(q, 0), g2_bcast(q, 1));
-    // clear_cofactor_g2 (h2c.hpp) with the doubling chains lane-parallel
-    g2_jac t1 = g2_mul_x_coop(p);
+// clear_cofactor_g2 (h2c.hpp) with the two 64-doubling chains lane-parallel
+__device__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
+    g2_jac t1 = g2_mul_x_coop(p, gbase, role);
     g2_jac t2 = g2_psi(p);
-    g2_jac t3 = g2_psi(g2_psi(g2_dbl_coop(p)));
+    g2_jac t3 = g2_psi(g2_psi(g2_dbl_coop(p, gbase, role)));
     t3 = jac_add(t3, jac_neg(t2));
     t2 = jac_add(t1, t2);
-    t2 = g2_mul_x_coop(t2);
+    t2 = g2_mul_x_coop(t2, gbase, role);
     t3 = jac_add(t3, t2);
     t3 = jac_add(t3, jac_neg(t1));
-    g2_jac h = jac_add(t3, jac_neg(p));
+    return jac_add(t3, jac_neg(p));
+}
+// ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
+// it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
+// their independent products over roles 0..2.  Every group of 8 lanes does the same work.
+__global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, uint4* __restrict__ H, size_t stride, size_t slot) {
+    const uint32_t role = threadIdx.x & 7u, gbase = threadIdx.x & ~7u;
+    fp2 u0, u1;
+    hash_to_field_fp2x2(u0, u1, msg, len, dst.b, dst.len);
+    g2_jac q = iso3_g2(sswu_g2(fp2_select(role == 1, u1, u0)));
+    g2_jac q0{fp2_from_role(q.x, gbase, 0), fp2_from_role(q.y, gbase, 0), fp2_from_role(q.z, gbase, 0)};
+    g2_jac q1{fp2_from_role(q.x, gbase, 1), fp2_from_role(q.y, gbase, 1), fp2_from_role(q.z, gbase, 1)};
+    g2_jac h = clear_cofactor_g2_coop(jac_add(q0, q1), gbase, role);
     if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, h);
+}
+// batch form for batches that would not fill the chip with one lane per message: 8 lanes per message
+__global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    const uint32_t role = threadIdx.x & 7u, gbase = threadIdx.x & ~7u;
+    uint32_t i = blockIdx.x * 8 + (threadIdx.x >> 3);
+    bool live = i < n;
+    if (!live) i = 0;
+    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
+    g2_jac h = clear_cofactor_g2_coop(jac_add(q0, q1), gbase, role);
+    if (live && role == 0) soa_st_g2(H, stride, i, h);
 }
 
 __global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
@@ -339,7 +366,7 @@ __global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ set
     if (i < n) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * stride_b + offset_b);
         g2_aff s = ld_g2a_blst(w);
-        acc = jac_mul_u64(s, r[i]);                 // infinity signature -> infinity (contributes nothing)
+        acc = jac_mul_u64_w4(s, r[i]);              // infinity signature -> infinity (contributes nothing)
     }
     for (int d = 32; d >= 1; d >>= 1) {
         g2_jac o = shfl_down_struct(acc, d);
@@ -387,23 +414,6 @@ __global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ pa
 // times per step instead of 15.  Same formulas, carries and reductions as miller_dbl_step; the 5 addition steps run
 // redundantly in every lane.  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.9 ms).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ fp2 fp2_from_role(const fp2& a, uint32_t gbase, uint32_t role) {
-    fp2 r;
-    int src = (int)(gbase + role);
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) {
-        r.c0.l[i] = __shfl(a.c0.l[i], src, WAVE);
-        r.c1.l[i] = __shfl(a.c1.l[i], src, WAVE);
-    }
-    return r;
-}
-__device__ __forceinline__ fp fp_from_role(const fp& a, uint32_t gbase, uint32_t role) {
-    fp r;
-    int src = (int)(gbase + role);
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
-    return r;
-}
 __device__ __forceinline__ line_t miller_dbl_step_coop(g2_proj& t, const g1_pre& p, uint32_t gbase, uint32_t role) {
     // round 1: B = Y^2 | C = Z^2 | X^2 | (Y+Z)^2 | (X+Y)^2
     fp2 YZs = fp2_add(t.y, t.z), XYs = fp2_add(t.x, t.y);
@@ -1511,7 +1521,10 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
-    k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+    if ((n32 + 7) / 8 <= c->slots)
+        k_hash_clear_coop<<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+    else
+        k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));
     k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[3], st));
