@@ -1381,7 +1381,7 @@ struct mi355_bls_ctx {
 };
 
 constexpr uint32_t SIG_SLOTS_MAX = 2048;     // 8 windows x 256 digits
-constexpr size_t SIG_BUCKET_MIN = 1024;      // below this the per-tuple 64-bit multiplications are cheaper than the extra pairs
+constexpr size_t SIG_BUCKET_MIN = 64;        // below this the per-tuple 64-bit multiplications are cheaper than the 256 extra pairs
 constexpr size_t SIG_WIDE_MIN = 40000;       // from here 8-bit digits (2048 extra pairs, 8 additions per tuple) beat 4-bit ones (256, 15)
 
 static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
@@ -1541,6 +1541,8 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, st>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
         uint32_t per = n32 >> cw, lshift = 0;                          // expected entries per bucket; ~16 per lane
         while (lshift < 6 && (per >> (lshift + 1)) >= 16) lshift++;
+        // small batches leave most of the chip idle: more lanes per bucket (down to ~2 entries per lane) shorten the kernel
+        while (lshift < 6 && ((total << (lshift + 1)) <= 16 * c->slots) && (per >> (lshift + 1)) >= 2) lshift++;
         k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
                                                                              c->d_sig_consts + (cw == 8 ? (size_t)SIG_SLOTS_MAX * G1W : 0), c->d_H, c->d_P,
                                                                              c->stride);
