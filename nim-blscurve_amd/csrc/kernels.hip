@@ -7,9 +7,9 @@
 //   k_hash_clear  one lane per tuple: sum of the two mapped points, cofactor clearing; Jacobian H_i
 //   k_pkmul       one lane per tuple: [r_i]PK_i (signed 4-bit windows), Jacobian; infinity-pk flag (blst pk part)
 //   signature side (blst sig part + finalverify's extra pair):
-//     n >= 1024: k_sig_convert, k_msm_hist/scan/scatter (counting sort by digit of r_i), k_sig_bucket: bucket
+//     n >= 64:   k_sig_convert, k_msm_hist/scan/scatter (counting sort by digit of r_i), k_sig_bucket: bucket
 //                sums B_{w,d} -> extra Miller pairs (-[d 2^(cw)]G1, B_{w,d})
-//     n <  1024: k_sigmul ([r_i]S_i, wave-shuffle sum) + k_sigsum -> AggrSign, appended as pair n with P = -G1
+//     n <  64:   k_sigmul ([r_i]S_i, wave-shuffle sum) + k_sigsum -> AggrSign, appended as pair n with P = -G1
 //   k_lines       one lane per pair: 68 Miller lines -> HBM, step-major SoA             (miller_loop_n)
 //   k_lineprod    (step, pair-range) grid: per-lane sparse products, wave-shuffle Fp12 product tree
 //   k_lineprod2   per step: product of the range partials -> L_s
