@@ -337,10 +337,18 @@ def cpu_baseline(co, sample, rnd):
     ok = co.batch_verify(recs, rnd, cores)
     dt = time.perf_counter() - t0
     assert ok
+    # one core (batchVerifySerial shape), a few seconds
+    n1 = min(1024, len(recs) // 320)
+    t0 = time.perf_counter()
+    assert co.batch_verify(recs[:320 * n1], rnd, 1)
+    dt1 = time.perf_counter() - t0
+    import ctypes.util
     return {"value": sample / dt, "unit": "verifications/s", "cores": cores, "kind": "port",
-            "sample": "%d tuples of the same workload, batchVerifyParallel shape with %d threads, %.1f s "
+            "value_1core": n1 / dt1,
+            "blst_on_this_box": bool(ctypes.util.find_library("blst")),      # use BLST itself if the box has it
+            "sample": "%d tuples of the same workload, batchVerifyParallel shape with %d threads, %.1f s; 1 core: %d tuples, %.1f s "
                       "(oracle/bls_oracle.c: unoptimised plain-C restatement of the reference algorithm, not BLST; "
-                      "BLST's assembly is several times faster per core)" % (sample, cores, dt)}
+                      "BLST's assembly is several times faster per core)" % (sample, cores, dt, n1, dt1)}
 
 
 if __name__ == "__main__":
