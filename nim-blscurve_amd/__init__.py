@@ -48,6 +48,7 @@ def lib():
         L.mi355_bls_ctx_destroy.restype = None
         L.mi355_bls_last_error.restype = ctypes.c_char_p
         L.mi355_bls_ctx_set_num_threads.argtypes = [vp, u32]
+        L.mi355_bls_ctx_set_cooperative.argtypes = [vp, i32]
         L.mi355_bls_batch_verify.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_batch_verify_serial.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_batch_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp]
@@ -144,6 +145,10 @@ class BatchedBLSVerifierCache:
             pass
 
     # -- stage outputs of the last call (parity tests) --
+    def set_cooperative(self, on):
+        """Small batches: 8 lanes per set (latency, default) or one lane per set (throughput with many batches in flight)."""
+        _check(lib().mi355_bls_ctx_set_cooperative(self._h, 1 if on else 0))
+
     def fetch(self, what, nbytes):
         b = ctypes.create_string_buffer(nbytes)
         _check(lib().mi355_bls_fetch_stage(self._h, what, b, nbytes))

@@ -1365,6 +1365,7 @@ struct mi355_bls_ctx {
     uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
     uint32_t* h_flags = nullptr;     // pinned host copy of d_flags[0..1] (asynchronous submit / wait)
     bool pending = false;            // a submitted batch has not been waited for yet
+    bool coop = true;                // small batches: lane-cooperative kernels (latency) instead of one lane per item (throughput)
     bool wide_recorded = false;      // ev_lp (end of the whole-chip kernels) has been recorded at least once
     hipStream_t pending_stream = nullptr;
     uint32_t* d_export = nullptr;
@@ -1484,6 +1485,12 @@ extern "C" int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* c, uint32_t nt) {
     return 0;
 }
 
+extern "C" int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* c, int on) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    c->coop = on != 0;
+    return 0;
+}
+
 extern "C" void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t lo, uint32_t hi, size_t* first, size_t* count) {
     size_t B = n_total < num_threads ? n_total : num_threads;
     if (B == 0 || lo >= hi) {
@@ -1500,7 +1507,7 @@ extern "C" void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint
 
 // Miller lines of pairs 0 .. npairs-1: the 8-lanes-per-pair kernel while that does not take more waves than the chip has slots
 static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, hipStream_t st) {
-    if ((npairs + 7) / 8 <= c->slots)
+    if (c->coop && (npairs + 7) / 8 <= c->slots)
         k_lines_coop<<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
     else
         k_lines<<<(npairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
@@ -1521,7 +1528,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
-    if ((n32 + 7) / 8 <= c->slots)
+    if (c->coop && (n32 + 7) / 8 <= c->slots)
         k_hash_clear_coop<<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     else
         k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);

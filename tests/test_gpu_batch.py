@@ -147,6 +147,25 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
     assert co.batch_verify(bytes(bad), rnd, nt) is False
 
 
+def test_cooperative_and_plain_kernels_agree(m):
+    """Batches that do not fill the chip use 8 lanes per set by default; the one-lane-per-set kernels must give the same
+    H(m_i) points, GT value and verdict."""
+    import c_oracle as co
+    n = 600
+    rec = co.make_batch(n, seed=31337)
+    rnd = o.sha256(b"Mr F was here")
+    a = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=64)
+    b = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=64)
+    b.set_cooperative(False)
+    assert m.batchVerify(a, rec, rnd) is True and m.batchVerify(b, rec, rnd) is True
+    assert a.fetch(4, 576) == b.fetch(4, 576)
+    Ha, Hb = a.fetch(1, 288 * n), b.fetch(1, 288 * n)
+    for i in (0, 1, 299, n - 1):
+        assert g2_jac_to_affine(Ha[288 * i:288 * i + 288]) == g2_jac_to_affine(Hb[288 * i:288 * i + 288])
+    ok, st = co.batch_verify(rec, rnd, 64, stages=True)
+    assert ok and st["gt"] == a.fetch(4, 576)
+
+
 def test_submit_wait(m):
     """Asynchronous entry points: several contexts kept in flight from one host thread give the verdicts of the
     blocking call; a context takes one batch at a time."""
