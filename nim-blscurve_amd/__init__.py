@@ -92,6 +92,17 @@ def _check(rc):
     return rc
 
 
+def _rnd32(secureRandomBytes):
+    """secureRandomBytes is `array[32, byte]` in the reference (bls_batch_verifier.nim:301): exactly 32 bytes,
+    bytes-like.  (bytes(int) would silently give that many ZERO bytes, a short buffer lets the C side read past it.)"""
+    if not isinstance(secureRandomBytes, (bytes, bytearray, memoryview)):
+        raise ValueError("secureRandomBytes must be a bytes-like object of 32 bytes")
+    b = bytes(secureRandomBytes)
+    if len(b) != 32:
+        raise ValueError("secureRandomBytes must be exactly 32 bytes, got %d" % len(b))
+    return b
+
+
 def pack_signature_sets(sets):
     """[(pubkey96, message32, signature192)] -> contiguous 320-byte records (the Nim tuple layout)."""
     out = bytearray()
@@ -168,12 +179,12 @@ class BatchedBLSVerifierCache:
 
     # -- device-resident entry points --
     def verify_device(self, d_ptr, n, secureRandomBytes, stream=0):
-        return bool(_check(lib().mi355_bls_batch_verify_device(self._h, d_ptr, n, bytes(secureRandomBytes), stream)))
+        return bool(_check(lib().mi355_bls_batch_verify_device(self._h, d_ptr, n, _rnd32(secureRandomBytes), stream)))
 
     def submit_device(self, d_ptr, n, secureRandomBytes, stream=0, after=None):
         """Enqueue a batch verification and return at once; wait() gives its verdict.  after: a context whose
         batch was submitted before; this one then starts beside that batch's serial tail."""
-        _check(lib().mi355_bls_batch_submit_device(self._h, d_ptr, n, bytes(secureRandomBytes), stream, after._h if after is not None else None))
+        _check(lib().mi355_bls_batch_submit_device(self._h, d_ptr, n, _rnd32(secureRandomBytes), stream, after._h if after is not None else None))
 
     def wait(self):
         return bool(_check(lib().mi355_bls_batch_wait(self._h)))
@@ -181,11 +192,11 @@ class BatchedBLSVerifierCache:
     def shard_device(self, d_ptr, n_total, chunk_lo, chunk_hi, secureRandomBytes, stream=0):
         out = ctypes.create_string_buffer(576)
         ok = ctypes.c_int()
-        _check(lib().mi355_bls_batch_shard_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, bytes(secureRandomBytes), stream, out, ctypes.byref(ok)))
+        _check(lib().mi355_bls_batch_shard_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, _rnd32(secureRandomBytes), stream, out, ctypes.byref(ok)))
         return out.raw, bool(ok.value)
 
     def shard_submit_device(self, d_ptr, n_total, chunk_lo, chunk_hi, secureRandomBytes, stream=0, after=None):
-        _check(lib().mi355_bls_batch_shard_submit_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, bytes(secureRandomBytes), stream,
+        _check(lib().mi355_bls_batch_shard_submit_device(self._h, d_ptr, n_total, chunk_lo, chunk_hi, _rnd32(secureRandomBytes), stream,
                                                          after._h if after is not None else None))
 
     def shard_wait(self):
@@ -205,7 +216,7 @@ def batchVerifySerial(cache, input_, secureRandomBytes):
     n = len(rec) // SIGSET_BYTES
     if n == 0:
         return False
-    return bool(_check(lib().mi355_bls_batch_verify_serial(cache._h, rec, n, bytes(secureRandomBytes))))
+    return bool(_check(lib().mi355_bls_batch_verify_serial(cache._h, rec, n, _rnd32(secureRandomBytes))))
 
 
 def batchVerifyParallel(cache, input_, secureRandomBytes):
@@ -214,7 +225,7 @@ def batchVerifyParallel(cache, input_, secureRandomBytes):
     n = len(rec) // SIGSET_BYTES
     if n == 0:
         return False
-    return bool(_check(lib().mi355_bls_batch_verify(cache._h, rec, n, bytes(secureRandomBytes))))
+    return bool(_check(lib().mi355_bls_batch_verify(cache._h, rec, n, _rnd32(secureRandomBytes))))
 
 
 def batchVerify(cache, input_, secureRandomBytes):
@@ -299,7 +310,7 @@ def batchVerifyCompressed(cache, pubkeys, messages, signatures, secureRandomByte
     if n == 0:
         return False, b""
     st = ctypes.create_string_buffer(n)
-    ok = _check(lib().mi355_bls_batch_verify_compressed(cache._h, pk, ms, sg, n, bytes(secureRandomBytes), st))
+    ok = _check(lib().mi355_bls_batch_verify_compressed(cache._h, pk, ms, sg, n, _rnd32(secureRandomBytes), st))
     return bool(ok), st.raw
 
 
@@ -352,7 +363,7 @@ class MultiSignatureSet:
         """-> SignatureSet (pubkey96, message32, signature192)."""
         n = len(self.pubkeys)
         out_pk, out_sig = ctypes.create_string_buffer(96), ctypes.create_string_buffer(192)
-        _check(lib().mi355_bls_combine(cache._h, bytes(secureRandomBytes), b"".join(self.pubkeys), b"".join(self.signatures), n, out_pk, out_sig))
+        _check(lib().mi355_bls_combine(cache._h, _rnd32(secureRandomBytes), b"".join(self.pubkeys), b"".join(self.signatures), n, out_pk, out_sig))
         return (out_pk.raw, self.message, out_sig.raw)
 
 

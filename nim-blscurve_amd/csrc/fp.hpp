@@ -425,7 +425,6 @@ BLS_HD fp fp_canon(const fp& a) {
     BLS_SET_LB(u, 0);
     return u;
 }
-BLS_HD fp fp_canon_lt2p(const fp& t) { return fp_canon(t); }
 
 BLS_HD bool fp_limbs_are_zero(const fp& a) {
     uint32_t acc = 0;
@@ -433,11 +432,9 @@ BLS_HD bool fp_limbs_are_zero(const fp& a) {
     for (int i = 0; i < FP_N; i++) acc |= a.l[i];
     return acc == 0;
 }
-BLS_HD bool fp_is_zero_any(const fp& a) { return fp_is_zero(a); }
-BLS_HD bool fp_eq_any(const fp& a, const fp& b) { return fp_eq(a, b); }
 
 // Montgomery -> plain integer, canonical limbs
-BLS_HD fp fp_from_mont(const fp& a) { return fp_canon_lt2p(fp_mul(a, fp_from_const(k::PLAIN_ONE))); }
+BLS_HD fp fp_from_mont(const fp& a) { return fp_canon(fp_mul(a, fp_from_const(k::PLAIN_ONE))); }
 
 // plain integer < 2^392 given as 28-bit limbs (value bound set by the caller) -> Montgomery
 BLS_HD fp fp_to_mont(const fp& a) { return fp_mul(a, fp_from_const(k::RR)); }
@@ -473,7 +470,7 @@ BLS_HD fp fp_from_blst(const uint32_t (&w)[12]) {
     return fp_mul(v, fp_from_const(k::C400));
 }
 BLS_HD void fp_to_blst(uint32_t (&w)[12], const fp& a) {
-    fp r = fp_canon_lt2p(fp_mul(a, fp_from_const(k::C384)));   // x * 2^384 mod p
+    fp r = fp_canon(fp_mul(a, fp_from_const(k::C384)));   // x * 2^384 mod p
     fp_relimb_to32(w, r);
 }
 
@@ -545,9 +542,7 @@ BLS_HD fp2 fp2_from_const(const uint32_t (&c)[2 * FP_N]) {
 BLS_HD fp2 fp2_zero() { return fp2{fp_zero(), fp_zero()}; }
 BLS_HD fp2 fp2_one() { return fp2{fp_one(), fp_zero()}; }
 BLS_HD bool fp2_is_zero(const fp2& a) { return fp_is_zero(a.c0) & fp_is_zero(a.c1); }
-BLS_HD bool fp2_is_zero_any(const fp2& a) { return fp_is_zero_any(a.c0) & fp_is_zero_any(a.c1); }
 BLS_HD bool fp2_eq(const fp2& a, const fp2& b) { return fp_eq(a.c0, b.c0) & fp_eq(a.c1, b.c1); }
-BLS_HD bool fp2_eq_any(const fp2& a, const fp2& b) { return fp_eq_any(a.c0, b.c0) & fp_eq_any(a.c1, b.c1); }
 BLS_HD fp2 fp2_select(bool c, const fp2& a, const fp2& b) { return fp2{fp_select(c, a.c0, b.c0), fp_select(c, a.c1, b.c1)}; }
 BLS_HD fp2 fp2_add(const fp2& a, const fp2& b) { return fp2{fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
 BLS_HD fp2 fp2_sub(const fp2& a, const fp2& b) { return fp2{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }

@@ -179,7 +179,7 @@ BLS_MID g2_jac sswu_g2(const fp2& u) {
     fp2 tv1 = fp2_mul(Z, fp2_sqr(u));
     fp2 tv2 = fp2_add(fp2_sqr(tv1), tv1);
     fp2 xn = fp2_mul(B, fp2_add(tv2, fp2_one()));                 // x1 numerator
-    fp2 xd = fp2_select(fp2_is_zero_any(tv2), fp2_from_const(k::SSWU_ZA), fp2_mul(A, fp2_neg(tv2)));
+    fp2 xd = fp2_select(fp2_is_zero(tv2), fp2_from_const(k::SSWU_ZA), fp2_mul(A, fp2_neg(tv2)));
     fp2 xd2 = fp2_sqr(xd);
     fp2 D = fp2_mul(xd2, xd);
     fp2 N = fp2_add(fp2_mul(fp2_add(fp2_sqr(xn), fp2_mul(A, xd2)), xn), fp2_mul(B, D));

@@ -202,34 +202,28 @@ __device__ __forceinline__ fp fp_from_role(const fp& a, uint32_t gbase, uint32_t
 
 // ------------------------------------------------------------------------------------------
 // k_blind: chunk c of B (parallel_chunks.nim:42-66) -> seed = SHA256(rnd || LE64(c)), then per tuple
-// seed <- SHA256(seed) until low u64 != 0 (blst_min_pubkey_sig_core.nim:497-507,:545-556).
-// serial != 0: one chain seeded SHA256(rnd) (batchVerifySerial, core :502-505).
+// seed <- SHA256(seed) until low u64 != 0 (blst_min_pubkey_sig_core.nim:497-507,:545-556).  One lane per chain.
+// (batchVerifySerial's single chain is computed on the host: host_serial_chain.)
 // Tuples are addressed relative to tuple_base (first tuple of this shard).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd, uint64_t n_total, uint32_t nchunks, uint32_t chunk_lo,
-                                                uint32_t chunk_cnt, uint64_t tuple_base, int serial, uint64_t* __restrict__ r_out) {
+                                                uint32_t chunk_cnt, uint64_t tuple_base, uint64_t* __restrict__ r_out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunk_cnt) return;
     uint64_t c = (uint64_t)chunk_lo + t;
     uint64_t off, len;
-    if (serial) {
-        off = 0;
-        len = n_total;
+    uint64_t base = n_total / nchunks, rem = n_total % nchunks;
+    if (c < rem) {
+        off = (base + 1) * c;
+        len = base + 1;
     } else {
-        uint64_t base = n_total / nchunks, rem = n_total % nchunks;
-        if (c < rem) {
-            off = (base + 1) * c;
-            len = base + 1;
-        } else {
-            off = base * c + rem;
-            len = base;
-        }
+        off = base * c + rem;
+        len = base;
     }
     sha256_ctx ctx;
     sha256_begin(ctx);
     for (int i = 0; i < 32; i++) sha256_put(ctx, rnd[i]);
-    if (!serial)
-        for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
+    for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
     uint32_t seed[8];
     sha256_end(ctx, seed);
     for (uint64_t j = 0; j < len; j++) {
@@ -1165,28 +1159,6 @@ __global__ void __launch_bounds__(WAVE) k_deser(const uint8_t* __restrict__ pks,
 //   s_i: chain seeded with rnd ITSELF, u64 words 3,2,1,0 of every digest, zeros skipped (:588-606)
 //   pk' = sum [s_i]PK_i, sig' = sum [s_i]S_i  (the reference's two 64-bit Pippenger calls, :629-646)
 // ------------------------------------------------------------------------------------------
-__global__ void k_combine_scalars(const uint8_t* __restrict__ rnd, uint32_t n, uint64_t* __restrict__ s_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t seed[8];
-    for (int i = 0; i < 8; i++) seed[i] = ((uint32_t)rnd[4 * i] << 24) | ((uint32_t)rnd[4 * i + 1] << 16) | ((uint32_t)rnd[4 * i + 2] << 8) | rnd[4 * i + 3];
-    int avail = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        for (;;) {
-            if (avail == 0) {
-                uint32_t nx[8];
-                sha256_of_digest(seed, nx);
-                for (int j = 0; j < 8; j++) seed[j] = nx[j];
-                avail = 4;
-            }
-            avail--;
-            uint64_t w = (uint64_t)bswap32(seed[2 * avail]) | ((uint64_t)bswap32(seed[2 * avail + 1]) << 32);   // LE u64 word `avail`
-            if (w != 0) {
-                s_out[i] = w;
-                break;
-            }
-        }
-    }
-}
 __global__ void __launch_bounds__(WAVE) k_g1mul_sum(const uint8_t* __restrict__ pts, size_t stride_b, size_t offset_b, uint32_t n, const uint64_t* __restrict__ r,
                                                     uint32_t* __restrict__ part) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1378,6 +1350,7 @@ struct mi355_bls_ctx {
     float timings[8] = {};
     dst_t dst;
     xmd32_consts xmd;                // message-independent SHA-256 words of expand_message_xmd for this DST
+    std::vector<uint64_t> h_r;       // host-computed scalar chains (serial blinding chain, combine)
     msm_ws* msm = nullptr;           // lazily sized MSM workspace
 };
 
@@ -1409,17 +1382,8 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     delete c;
 }
 
-extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets) {
-    if (!out || max_sets == 0 || max_sets > (1u << 30)) return MI355_BLS_ERR_ARG;
-    *out = nullptr;
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) {
-        g_err = "no such HIP device";
-        return MI355_BLS_ERR_HIP;
-    }
-    HIPCHK(hipSetDevice(device));
-    auto* c = new mi355_bls_ctx();
+// everything of ctx_create that can fail after the context object exists: any failure destroys it (no leaked device buffers)
+static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     c->device = device;
     c->msm = new msm_ws();
     c->cap = max_sets;
@@ -1428,16 +1392,17 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     c->dst.len = sizeof(DST_SIG) - 1;
     std::memcpy(c->dst.b, DST_SIG, c->dst.len);
     c->xmd = xmd32_precompute(c->dst.b, c->dst.len);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->slots = 4u * (uint32_t)prop.multiProcessorCount;
     size_t nwaves = c->stride / 64;
-#define ALLOC(p, bytes)                                   \
-    do {                                                  \
-        hipError_t e_ = hipMalloc((void**)&(p), (bytes)); \
-        if (e_ != hipSuccess) {                           \
-            g_err = std::string("hipMalloc " #p ": ") + hipGetErrorString(e_); \
-            mi355_bls_ctx_destroy(c);                     \
-            return MI355_BLS_ERR_HIP;                     \
-        }                                                 \
-    } while (0)
+    // k_lineprod hands over (68 steps x nblk ranges x 64 lanes) partial products; nblk <= slots / 68, and never more ranges than waves of pairs
+    uint32_t nblk = c->slots / N_LINES;
+    if (nblk < 1) nblk = 1;
+    if (nblk > 64) nblk = 64;
+    if (nblk > nwaves) nblk = (uint32_t)nwaves;
+    c->nblk_cap = nblk;
+#define ALLOC(p, bytes) HIPCHK(hipMalloc((void**)&(p), (bytes)))
     ALLOC(c->d_sets, max_sets * 320);
     ALLOC(c->d_rnd, 32);
     ALLOC(c->d_r, c->stride * 8);
@@ -1461,20 +1426,39 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_flags, 16);
-    HIPCHK(hipHostMalloc((void**)&c->h_flags, 1024, hipHostMallocDefault));    // words 0..3 flags, 4..11 staging copy of rnd, 16..159 shard state
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
+    HIPCHK(hipHostMalloc((void**)&c->h_flags, 1024, hipHostMallocDefault));    // words 0..3 flags, 4..11 staging copy of rnd, 16..159 shard state
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreate(&c->ev_hm));
     HIPCHK(hipEventCreate(&c->ev_lp));
     HIPCHK(hipEventCreate(&c->ev_deser0));
     HIPCHK(hipEventCreate(&c->ev_deser1));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    c->slots = 4u * (uint32_t)prop.multiProcessorCount;
     k_sig_consts<<<(256 + WAVE - 1) / WAVE, WAVE>>>(4, 256, c->d_sig_consts);
     k_sig_consts<<<(2048 + WAVE - 1) / WAVE, WAVE>>>(8, 2048, c->d_sig_consts + (size_t)SIG_SLOTS_MAX * G1W);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets) {
+    if (!out || max_sets == 0 || max_sets > (1u << 30)) return MI355_BLS_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        g_err = "no such HIP device";
+        return MI355_BLS_ERR_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    auto* c = new mi355_bls_ctx();
+    int rc = ctx_build(c, device, max_sets);
+    if (rc) {
+        std::string keep = g_err;
+        mi355_bls_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
     return 0;
 }
@@ -1505,6 +1489,51 @@ extern "C" void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint
     *count = off(hi) - off(lo);      // off(B) == n_total
 }
 
+// The two inherently serial SHA-256 chains of the reference run on the HOST (one GPU lane needs ~4 us per compression:
+// 65 536 links = a quarter of a second; one CPU core does them in a few milliseconds):
+//   batchVerifySerial's single blinding chain (core :502-505, :545-556): seed = SHA256(rnd), then per tuple
+//   seed <- SHA256(seed) until the low u64 is non-zero;
+//   combine's chain (core :588-606): seeded with rnd itself, u64 words 3,2,1,0 of every digest, zeros skipped.
+static void host_sha256_32(const uint32_t (&in)[8], uint32_t (&out)[8]) {        // SHA-256 of 32 bytes given as 8 big-endian words
+    uint32_t w[16] = {in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], 0x80000000u, 0, 0, 0, 0, 0, 0, 256};
+    sha256_init(out);
+    sha256_compress_core(out, w);
+}
+static void host_serial_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
+    uint32_t seed[8], nx[8];
+    for (int i = 0; i < 8; i++) nx[i] = ((uint32_t)rnd[4 * i] << 24) | ((uint32_t)rnd[4 * i + 1] << 16) | ((uint32_t)rnd[4 * i + 2] << 8) | rnd[4 * i + 3];
+    host_sha256_32(nx, seed);
+    for (size_t j = 0; j < n; j++) {
+        uint64_t r;
+        do {
+            host_sha256_32(seed, nx);
+            for (int i = 0; i < 8; i++) seed[i] = nx[i];
+            r = digest_low_u64_le(seed);
+        } while (r == 0);
+        out[j] = r;
+    }
+}
+static void host_combine_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
+    uint32_t seed[8], nx[8];
+    for (int i = 0; i < 8; i++) seed[i] = ((uint32_t)rnd[4 * i] << 24) | ((uint32_t)rnd[4 * i + 1] << 16) | ((uint32_t)rnd[4 * i + 2] << 8) | rnd[4 * i + 3];
+    int avail = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (;;) {
+            if (avail == 0) {
+                host_sha256_32(seed, nx);
+                for (int j = 0; j < 8; j++) seed[j] = nx[j];
+                avail = 4;
+            }
+            avail--;
+            uint64_t w = (uint64_t)bswap32(seed[2 * avail]) | ((uint64_t)bswap32(seed[2 * avail + 1]) << 32);   // LE u64 word `avail`
+            if (w != 0) {
+                out[i] = w;
+                break;
+            }
+        }
+    }
+}
+
 // Miller lines of pairs 0 .. npairs-1: the 8-lanes-per-pair kernel while that does not take more waves than the chip has slots
 static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, hipStream_t st) {
     if (c->coop && (npairs + 7) / 8 <= c->slots)
@@ -1524,7 +1553,13 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     uint32_t n32 = (uint32_t)n;
     uint32_t nb = (n32 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
-    k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, serial, c->d_r);
+    if (serial) {
+        c->h_r.resize(n);
+        host_serial_chain(rnd, n, c->h_r.data());
+        HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), n * 8, hipMemcpyHostToDevice, st));
+    } else {
+        k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, c->d_r);
+    }
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
@@ -1639,6 +1674,7 @@ static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, con
 static int verify_wait(mi355_bls_ctx* c) {
     if (!c || !c->pending) return MI355_BLS_ERR_ARG;
     c->pending = false;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->pending_stream));
     c->have_gt = true;
     float fin = 0;
@@ -1714,6 +1750,7 @@ static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, u
 static int shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) {
     if (!c || !out_fp12 || !out_ok || !c->pending) return MI355_BLS_ERR_ARG;
     c->pending = false;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->pending_stream));
     std::memcpy(out_fp12, c->h_flags + 16, 576);
     *out_ok = c->h_flags[0] == 0 ? 1 : 0;
@@ -1737,6 +1774,7 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_states, fp12s, kk * 576, hipMemcpyHostToDevice, nullptr));
     k_tail<<<1, WAVE, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1);
+    HIPCHK(hipGetLastError());
     uint32_t v = 0;
     HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
@@ -1757,11 +1795,13 @@ extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size
         case 1:
             if (out_bytes < n * 288 || n == 0) return MI355_BLS_ERR_ARG;
             k_export_g2<<<nb, 64>>>(c->d_H, c->stride, (uint32_t)n, c->d_export);
+            HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpy(out, c->d_export, n * 288, hipMemcpyDeviceToHost));
             return 0;
         case 2:
             if (out_bytes < n * 144 || n == 0) return MI355_BLS_ERR_ARG;
             k_export_g1<<<nb, 64>>>(c->d_P, c->stride, (uint32_t)n, c->d_export);
+            HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpy(out, c->d_export, n * 144, hipMemcpyDeviceToHost));
             return 0;
         case 3:
@@ -1814,7 +1854,7 @@ static int g1_sum_enqueue(mi355_bls_ctx* c, const uint8_t* d_pts, size_t n, hipS
 }
 
 extern "C" int mi355_bls_g1_aggregate_device(mi355_bls_ctx* c, const void* d_pks, size_t n, void* stream, uint8_t out_p1[144]) {
-    if (!c || !d_pks || !out_p1 || n == 0) return MI355_BLS_ERR_ARG;
+    if (!c || !d_pks || !out_p1 || n == 0 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], st));
@@ -1839,7 +1879,7 @@ extern "C" int mi355_bls_g1_aggregate(mi355_bls_ctx* c, const void* pks, size_t 
 
 extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
                                                       const void* sig, void* stream) {
-    if (!c || !sig || (!msg && msg_len) || msg_len > 4096) return MI355_BLS_ERR_ARG;
+    if (!c || !sig || (!msg && msg_len) || msg_len > 4096 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;                                     // bls_sig_min_pubkey.nim:251-253
     if (!d_pks) return MI355_BLS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -2150,10 +2190,11 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
     uint8_t* d_sg = c->d_sets + n * 96;
     HIPCHK(hipMemcpyAsync(d_pk, pks, n * 96, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_sg, sigs, n * 192, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_rnd, rnd, 32, hipMemcpyHostToDevice, st));
     uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
-    k_combine_scalars<<<1, 1, 0, st>>>(c->d_rnd, n32, c->d_r);
+    c->h_r.resize(n);
+    host_combine_chain(rnd, n, c->h_r.data());
+    HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), n * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_g1mul_sum<<<nb, WAVE, 0, st>>>(d_pk, 96, 0, n32, c->d_r, c->d_export);
     k_g1_sum2<<<1, WAVE, 0, st>>>(c->d_export, nb, c->d_agg1);
@@ -2180,6 +2221,8 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     if (n == 0) return 0;                                   // "Spec precondition" (bls_sig_min_pubkey.nim:165-167)
     if (!pks || !msgs || !msg_offsets) return MI355_BLS_ERR_ARG;
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    for (size_t i = 0; i < n; i++)
+        if (msg_offsets[i] > msg_offsets[i + 1]) return MI355_BLS_ERR_ARG;      // offsets must be non-decreasing (lengths are differences)
     size_t total = msg_offsets[n];
     if (total + (n + 1) * 4 > c->cap * 320 - n * 96) return MI355_BLS_ERR_CAPACITY;     // staged in d_sets behind the keys
     HIPCHK(hipSetDevice(c->device));

@@ -57,8 +57,8 @@ BLS_HD fp12 fp12_one() { return fp12{fp6{fp2_one(), fp2_zero(), fp2_zero()}, fp6
 BLS_HD fp12 fp12_conj(const fp12& a) { return fp12{a.c0, fp6_neg(a.c1)}; }
 
 BLS_HD bool fp12_is_one(const fp12& a) {
-    return fp2_eq_any(a.c0.a0, fp2_one()) & fp2_is_zero_any(a.c0.a1) & fp2_is_zero_any(a.c0.a2) & fp2_is_zero_any(a.c1.a0) &
-           fp2_is_zero_any(a.c1.a1) & fp2_is_zero_any(a.c1.a2);
+    return fp2_eq(a.c0.a0, fp2_one()) & fp2_is_zero(a.c0.a1) & fp2_is_zero(a.c0.a2) & fp2_is_zero(a.c1.a0) &
+           fp2_is_zero(a.c1.a1) & fp2_is_zero(a.c1.a2);
 }
 
 // 3 fp6 multiplications (54 fp mul)

@@ -201,7 +201,7 @@ def test_submit_wait(m):
 
 @pytest.mark.parametrize("n", [1024, 2048, 39999, 40000, 40960])
 def test_bucket_fold_of_the_signature_side(m, n):
-    """n >= 1024: the signatures are folded into digit buckets that become extra Miller pairs (4-bit digits below
+    """n >= 64 (SIG_BUCKET_MIN): the signatures are folded into digit buckets that become extra Miller pairs (4-bit digits below
     40 000 tuples, 8-bit from there).  sum [r_i]S_i (folded from the buckets on demand) and the final GT value must
     still be the C restatement's, also with infinity signatures in the batch (they contribute nothing)."""
     import c_oracle as co
