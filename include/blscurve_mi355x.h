@@ -30,6 +30,7 @@ extern "C" {
 #define MI355_BLS_FP12_BYTES 576
 #define MI355_BLS_P1_BYTES 144
 #define MI355_BLS_P2_BYTES 288
+#define MI355_BLS_BLOB_BYTES 640     /* device-resident shard blob: 576-byte state | u32 ok word | zero padding */
 
 #define MI355_BLS_ERR_HIP (-1)       /* a HIP call failed; see mi355_bls_last_error() */
 #define MI355_BLS_ERR_CAPACITY (-2)  /* n exceeds the context's capacity */
@@ -59,7 +60,8 @@ int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* ctx, int on);
 int mi355_bls_batch_verify(mi355_bls_ctx* ctx, const void* sets, size_t n, const uint8_t rnd[32]);
 
 /* batchVerifySerial (bls_batch_verifier.nim:121-160): same check with the serial scalar chain
- * (seed = SHA256(rnd), one chain over the whole batch). */
+ * (seed = SHA256(rnd), one chain over the whole batch).  The chain is inherently sequential: it is computed on the calling
+ * host thread (about 0.3 us per tuple) and uploaded; everything else runs on the device as in the parallel path. */
 int mi355_bls_batch_verify_serial(mi355_bls_ctx* ctx, const void* sets, size_t n, const uint8_t rnd[32]);
 
 /* Same as mi355_bls_batch_verify with the records already resident in device memory (HBM) and
@@ -98,6 +100,37 @@ int mi355_bls_batch_shard_wait(mi355_bls_ctx* ctx, uint8_t out_fp12[576], int* o
  * memory, k x 576 B), one final exponentiation on the device, == 1. */
 int mi355_bls_finalverify_shards(mi355_bls_ctx* ctx, const uint8_t* fp12s, size_t k);
 
+/* Device-resident exchange for one-process-per-GPU callers (the multi-GPU bench): every shard submit also writes the shard's
+ * state + ok word into the context's blob buffer (MI355_BLS_BLOB_BYTES, device memory) on the submit's stream.  The caller
+ * gathers the blobs of all ranks with a collective on device buffers (RCCL all_gather, enqueued behind the submit on the same
+ * stream) and hands the gathered buffer to finalverify_blobs: merge (blst_pairing_merge, core :657-666) + finalVerify
+ * (:670-672) on k blobs `stride_bytes` apart in DEVICE memory, enqueued on `stream`; finalverify_wait blocks and returns the
+ * verdict (1 only if every shard's ok word is 1 and the product is one).  No host round trip between submit and verdict. */
+int mi355_bls_ctx_shard_blob_device(mi355_bls_ctx* ctx, void** d_blob);
+int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* ctx, const void* d_blobs, size_t k, size_t stride_bytes, void* stream);
+int mi355_bls_finalverify_wait(mi355_bls_ctx* ctx);
+
+/* Which chunks device `rank` of `world` takes: contiguous balanced blocks of the B = min(n_total, num_threads) chunks,
+ * and the tuple range they cover. */
+int mi355_bls_shard_plan(size_t n_total, uint32_t num_threads, uint32_t world, uint32_t rank, uint32_t* chunk_lo, uint32_t* chunk_hi,
+                         size_t* first, size_t* count);
+
+/* batchVerifyParallel across several GPUs of one node from ONE host thread (bls_batch_verifier.nim:296-371 with devices in
+ * place of taskpool threads): ctxs[g] is a context on device g (all with the same num_threads, each with capacity for its
+ * shard, ceil(n / ngpu) + 1 sets is enough); shard g = the chunk block mi355_bls_shard_plan gives rank g.  All shards are
+ * enqueued asynchronously (:342-357), their 576-byte states return through pinned host memory, ctxs[0] merges them and runs
+ * the one final exponentiation (:360-371).  `sets`: n x 320 B in host memory; the _device form takes d_sets[g] = shard g's
+ * records already resident on device g.  n == 0 -> 0. */
+int mi355_bls_batch_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* sets, size_t n, const uint8_t rnd[32]);
+int mi355_bls_batch_verify_multi_device(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* const d_sets[], size_t n, const uint8_t rnd[32]);
+
+/* The cache-less overloads batchVerifyParallel(tp, input, rnd) / batchVerify(tp, input, rnd) (bls_batch_verifier.nim:399-416,
+ * :475-495), which build a BatchedBLSVerifierCache per call: here a process-wide default context (HIP device
+ * $MI355_BLS_DEVICE, default 0) created on first use and regrown on demand; calls are serialised by a mutex.
+ * num_threads = tp.numThreads; dispatch as batchVerify: parallel iff num_threads > 1 and n >= 3, else the serial chain. */
+int mi355_bls_batch_verify_once(const void* sets, size_t n, const uint8_t rnd[32], uint32_t num_threads);
+void mi355_bls_default_ctx_release(void);
+
 /* Helper: tuple range [*first, *first + *count) covered by chunks [chunk_lo, chunk_hi) of a batch of
  * n_total sets split into num_threads chunks (parallel_chunks.nim:42-66). */
 void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t chunk_lo, uint32_t chunk_hi, size_t* first, size_t* count);
@@ -124,6 +157,19 @@ int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* ctx, const void* d_pks
 size_t mi355_bls_p1s_mult_pippenger_scratch_sizeof(size_t npoints);
 int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* const points[], size_t npoints,
                                  const uint8_t* const scalars[], size_t nbits);
+/* EXACTLY blst_p1s_mult_pippenger / blst_p1s_mult_pippenger_scratch_sizeof (blst+nim.h:70-72; blst_abi.nim:336-340): same
+ * argument list and void result, so `importc: "mi355_p1s_mult_pippenger"` replaces the BLST symbol with no other change at
+ * the call sites (benchmarks/bls12381_msm_g1.nim:47-59; blst_min_pubkey_sig_core.nim:629-636).  blst's conventions:
+ *   points[] / scalars[]: list[0] points at element 0; each following element is taken from the next list entry if that is
+ *     non-NULL, else it follows the previous element in memory ([ptr, NULL] = one contiguous array; npoints pointers = one
+ *     per element);
+ *   scalars are little-endian, (nbits + 7) / 8 bytes each (32 for nbits = 255, 8 for the u64 scalars of `combine`);
+ *   ret: blst_p1 (Jacobian, 144 B); scratch: ignored (the workspace lives on the device; scratch_sizeof returns 8).
+ * Runs on the process-wide default context.  A runtime failure (no GPU, HIP error) cannot be returned through a void
+ * signature: the function prints the error and aborts. */
+size_t mi355_p1s_mult_pippenger_scratch_sizeof(size_t npoints);
+void mi355_p1s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch);
+
 /* same with both arrays resident in device memory */
 int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_points, size_t npoints,
                                         const void* d_scalars, size_t nbits, void* stream);

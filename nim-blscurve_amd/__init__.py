@@ -60,6 +60,19 @@ def lib():
         L.mi355_bls_finalverify_shards.argtypes = [vp, ctypes.c_char_p, sz]
         L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mi355_bls_chunk_range.restype = None
+        L.mi355_bls_ctx_shard_blob_device.argtypes = [vp, ctypes.POINTER(vp)]
+        L.mi355_bls_finalverify_blobs_submit_device.argtypes = [vp, vp, sz, sz, vp]
+        L.mi355_bls_finalverify_wait.argtypes = [vp]
+        L.mi355_bls_shard_plan.argtypes = [sz, u32, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.mi355_bls_batch_verify_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, ctypes.c_char_p]
+        L.mi355_bls_batch_verify_multi_device.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, ctypes.c_char_p]
+        L.mi355_bls_batch_verify_once.argtypes = [vp, sz, ctypes.c_char_p, u32]
+        L.mi355_bls_default_ctx_release.argtypes = []
+        L.mi355_bls_default_ctx_release.restype = None
+        L.mi355_p1s_mult_pippenger_scratch_sizeof.argtypes = [sz]
+        L.mi355_p1s_mult_pippenger_scratch_sizeof.restype = sz
+        L.mi355_p1s_mult_pippenger.argtypes = [vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, vp]
+        L.mi355_p1s_mult_pippenger.restype = None
         L.mi355_bls_g1_aggregate.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
@@ -205,9 +218,58 @@ class BatchedBLSVerifierCache:
         _check(lib().mi355_bls_batch_shard_wait(self._h, out, ctypes.byref(ok)))
         return out.raw, bool(ok.value)
 
+    BLOB_BYTES = 640
+
+    def shard_blob_ptr(self):
+        """Device address of this context's shard blob (state | ok word), written by every shard submit on its stream."""
+        p = ctypes.c_void_p()
+        _check(lib().mi355_bls_ctx_shard_blob_device(self._h, ctypes.byref(p)))
+        return p.value
+
+    def finalverify_blobs_submit(self, d_blobs, k, stride=640, stream=0):
+        """merge + finalVerify on k gathered shard blobs resident in device memory; finalverify_wait() gives the verdict."""
+        _check(lib().mi355_bls_finalverify_blobs_submit_device(self._h, d_blobs, k, stride, stream))
+
+    def finalverify_wait(self):
+        return bool(_check(lib().mi355_bls_finalverify_wait(self._h)))
+
     def finalverify_shards(self, states):
         blob = b"".join(states)
         return bool(_check(lib().mi355_bls_finalverify_shards(self._h, blob, len(states))))
+
+
+def shard_plan(n_total, num_threads, world, rank):
+    """(chunk_lo, chunk_hi, first_tuple, tuple_count) of device `rank` (mi355_bls_shard_plan)."""
+    lo, hi, first, count = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_size_t(), ctypes.c_size_t()
+    _check(lib().mi355_bls_shard_plan(n_total, num_threads, world, rank, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(first), ctypes.byref(count)))
+    return lo.value, hi.value, first.value, count.value
+
+
+def batchVerifyMulti(caches, input_, secureRandomBytes):
+    """batchVerifyParallel over several devices from one host thread (mi355_bls_batch_verify_multi): caches[g] lives on
+    device g; all must share numThreads.  Empty input -> False."""
+    rec = _as_records(input_)
+    n = len(rec) // SIGSET_BYTES
+    if n == 0:
+        return False
+    arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
+    return bool(_check(lib().mi355_bls_batch_verify_multi(arr, len(caches), rec, n, _rnd32(secureRandomBytes))))
+
+
+def batchVerifyMulti_device(caches, d_ptrs, n, secureRandomBytes):
+    """Same with shard g's records already resident on device g (d_ptrs[g])."""
+    arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
+    ptrs = (ctypes.c_void_p * len(caches))(*d_ptrs)
+    return bool(_check(lib().mi355_bls_batch_verify_multi_device(arr, len(caches), ptrs, n, _rnd32(secureRandomBytes))))
+
+
+def batchVerifyOnce(input_, secureRandomBytes, numThreads=DEFAULT_NUM_THREADS):
+    """The cache-less overloads batchVerify(tp, input, rnd) (bls_batch_verifier.nim:475-495) on the process-wide default context."""
+    rec = _as_records(input_)
+    n = len(rec) // SIGSET_BYTES
+    if n == 0:
+        return False
+    return bool(_check(lib().mi355_bls_batch_verify_once(rec, n, _rnd32(secureRandomBytes), numThreads)))
 
 
 def batchVerifySerial(cache, input_, secureRandomBytes):
@@ -274,6 +336,32 @@ def p1s_mult_pippenger(cache, points, scalars, nbits=255):
     sl = (ctypes.c_void_p * 2)(ctypes.addressof(sb) if n else None, None)
     out = ctypes.create_string_buffer(144)
     _check(lib().mi355_bls_p1s_mult_pippenger(cache._h, out, pl, n, sl, nbits))
+    return out.raw
+
+
+def blst_p1s_mult_pippenger(points, scalars, nbits=255, per_element_pointers=False):
+    """mi355_p1s_mult_pippenger: EXACTLY blst_p1s_mult_pippenger's argument list (no context, void, scalars
+    (nbits + 7) // 8 bytes apart, NULL-terminated pointer lists).  per_element_pointers: pass one pointer per element instead
+    of [ptr, NULL] (both are blst conventions).  Returns the 144-byte blst_p1."""
+    sb = (nbits + 7) // 8
+    if len(points) % 96 or len(scalars) % sb or len(points) // 96 != len(scalars) // sb:
+        raise ValueError("points: n x 96 bytes, scalars: n x %d bytes" % sb)
+    n = len(points) // 96
+    out = ctypes.create_string_buffer(144)
+    if n == 0:
+        lib().mi355_p1s_mult_pippenger(out, None, 0, None, nbits, None)
+        return out.raw
+    pb = ctypes.create_string_buffer(bytes(points), len(points))
+    scb = ctypes.create_string_buffer(bytes(scalars), len(scalars))
+    pa, sa = ctypes.addressof(pb), ctypes.addressof(scb)
+    if per_element_pointers:
+        pl = (ctypes.c_void_p * n)(*[pa + 96 * i for i in range(n)])
+        sl = (ctypes.c_void_p * n)(*[sa + sb * i for i in range(n)])
+    else:
+        pl = (ctypes.c_void_p * 2)(pa, None)
+        sl = (ctypes.c_void_p * 2)(sa, None)
+    scratch = ctypes.create_string_buffer(max(8, lib().mi355_p1s_mult_pippenger_scratch_sizeof(n)))
+    lib().mi355_p1s_mult_pippenger(out, pl, n, sl, nbits, scratch)
     return out.raw
 
 

@@ -19,6 +19,8 @@
 // loads/stores of one limb group are contiguous across the wave (coalesced dwordx4).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -717,8 +719,10 @@ __device__ __noinline__ void c12_inv(c12_lds& S, int d, int a) {
 
 // One wave.  mode bit 0: Horner-combine the 68 step products L -> state slot 0 (Miller value);
 // bit 1: multiply the kk states and run the final exponentiation -> gt_out, verdict.
+// sstride: distance in words between the kk states (144 = packed blst_fp12 images); blob != 0: every state is followed by
+// its shard's ok word (1 = no update failed), and the verdict also requires all of them.
 __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
-                                               uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict) {
+                                               uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
     __shared__ c12_lds S;
     int lane = threadIdx.x;
     if (lane == 0) {
@@ -748,7 +752,7 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
     if (mode & 2) {
         c12_load(S, F, states);
         for (uint32_t i = 1; i < kk; i++) {
-            c12_load(S, X1, states + (size_t)i * 144);
+            c12_load(S, X1, states + (size_t)i * sstride);
             c12_mul(S, F, F, X1);
         }
         // easy part: t = conj(f)/f ; t = frob2(t) * t
@@ -780,6 +784,8 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         if (lane == 0) {
             bool one = fp2_eq(S.r[C][0], fp2_one());
             for (int i = 1; i < 6; i++) one = one & fp2_is_zero(S.r[C][i]);
+            if (blob)
+                for (uint32_t i = 0; i < kk; i++) one = one & (states[(size_t)i * sstride + 144] == 1u);
             *verdict = one ? 1u : 0u;
         }
     }
@@ -1265,6 +1271,11 @@ __global__ void __launch_bounds__(WAVE) k_sign_sig(const uint8_t* __restrict__ s
     st_fp_blst(o, x.c0); st_fp_blst(o + 12, x.c1); st_fp_blst(o + 24, y.c0); st_fp_blst(o + 36, y.c1);
 }
 
+// shard state for the device-resident exchange: 576-byte committed state, then the ok word (1 = no update failed), zero padding
+__global__ void k_pack_blob(const uint32_t* __restrict__ states, const uint32_t* __restrict__ flags, uint32_t* __restrict__ blob) {
+    for (uint32_t i = threadIdx.x; i < MI355_BLS_BLOB_BYTES / 4; i += blockDim.x) blob[i] = i < 144 ? states[i] : (i == 144 ? (flags[0] == 0 ? 1u : 0u) : 0u);
+}
+
 // Jacobian SoA -> AoS copies for stage inspection
 __global__ void k_export_g2(const uint4* __restrict__ H, size_t stride, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1334,6 +1345,9 @@ struct mi355_bls_ctx {
     uint32_t* d_L = nullptr;
     uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
     uint32_t* d_gt = nullptr;
+    uint32_t* d_blob = nullptr;      // shard state + ok word for the device-resident exchange (MI355_BLS_BLOB_BYTES)
+    bool fv_pending = false;         // a finalverify_blobs submit has not been waited for
+    hipStream_t fv_stream = nullptr;
     uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
     uint32_t* h_flags = nullptr;     // pinned host copy of d_flags[0..1] (asynchronous submit / wait)
     bool pending = false;            // a submitted batch has not been waited for yet
@@ -1365,7 +1379,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_blob, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -1425,6 +1439,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
+    ALLOC(c->d_blob, MI355_BLS_BLOB_BYTES);
     ALLOC(c->d_flags, 16);
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
@@ -1631,7 +1646,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     }
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1);
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[7], st));
     HIPCHK(hipGetLastError());
     c->last_n = n;
@@ -1664,7 +1679,7 @@ static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, con
     uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
     int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
     if (rc) return rc;
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1);
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[8], st));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 8, hipMemcpyDeviceToHost, st));
     c->pending = true;
@@ -1741,6 +1756,8 @@ static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, u
     }
     int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
     if (rc) return rc;
+    k_pack_blob<<<1, WAVE, 0, st>>>(c->d_states, c->d_flags, c->d_blob);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_flags + 16, c->d_states, 576, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4, hipMemcpyDeviceToHost, st));
     c->pending = true;
@@ -1773,13 +1790,158 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
     if (!c || !fp12s || kk == 0 || kk > 64) return MI355_BLS_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_states, fp12s, kk * 576, hipMemcpyHostToDevice, nullptr));
-    k_tail<<<1, WAVE, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1);
+    k_tail<<<1, WAVE, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipGetLastError());
     uint32_t v = 0;
     HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     c->have_gt = true;
     return v == 1 ? 1 : 0;
+}
+
+extern "C" int mi355_bls_ctx_shard_blob_device(mi355_bls_ctx* c, void** d_blob) {
+    if (!c || !d_blob) return MI355_BLS_ERR_ARG;
+    *d_blob = c->d_blob;
+    return 0;
+}
+
+// merge + finalVerify on k shard blobs resident in DEVICE memory (e.g. the output of an RCCL all_gather of every rank's
+// mi355_bls_ctx_shard_blob_device buffer): nothing crosses PCIe but the verdict word.
+extern "C" int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* c, const void* d_blobs, size_t kk, size_t stride_bytes, void* stream) {
+    if (!c || !d_blobs || kk == 0 || kk > 1024 || stride_bytes < 580 || (stride_bytes & 3)) return MI355_BLS_ERR_ARG;
+    if (c->fv_pending) {
+        g_err = "a finalverify submitted on this context has not been waited for";
+        return MI355_BLS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
+                               (uint32_t)(stride_bytes / 4), 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_flags + 3, c->d_flags + 3, 4, hipMemcpyDeviceToHost, st));
+    c->fv_pending = true;
+    c->fv_stream = st;
+    return 0;
+}
+extern "C" int mi355_bls_finalverify_wait(mi355_bls_ctx* c) {
+    if (!c || !c->fv_pending) return MI355_BLS_ERR_ARG;
+    c->fv_pending = false;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->fv_stream));
+    c->have_gt = true;
+    return c->h_flags[3] == 1 ? 1 : 0;
+}
+
+// Contiguous, balanced blocks of chunks per device (the +-1 rule parallel_chunks uses for tuples, applied to chunks).
+extern "C" int mi355_bls_shard_plan(size_t n_total, uint32_t num_threads, uint32_t world, uint32_t rank, uint32_t* chunk_lo, uint32_t* chunk_hi,
+                                    size_t* first, size_t* count) {
+    if (world == 0 || rank >= world || num_threads == 0 || !chunk_lo || !chunk_hi || !first || !count) return MI355_BLS_ERR_ARG;
+    uint32_t B = (uint32_t)(n_total < num_threads ? n_total : num_threads);
+    uint32_t base = B / world, rem = B % world;
+    uint32_t lo = rank < rem ? (base + 1) * rank : base * rank + rem, hi = lo + base + (rank < rem ? 1 : 0);
+    *chunk_lo = lo;
+    *chunk_hi = hi;
+    if (lo < hi) {
+        mi355_bls_chunk_range(n_total, num_threads, lo, hi, first, count);
+    } else {                                                  // more devices than chunks: an empty shard at the end of the batch
+        size_t f0;
+        mi355_bls_chunk_range(n_total, num_threads, 0, lo, &f0, first);
+        *count = 0;
+    }
+    return 0;
+}
+
+// batchVerifyParallel over several GPUs from ONE host thread (bls_batch_verifier.nim:296-371 with devices in place of threads):
+// device g takes a contiguous block of chunks (its processSingleChunk work, :326-357), all shards are enqueued asynchronously,
+// the 576-byte committed states come back through pinned host memory, and device 0 merges them and runs the one final
+// exponentiation (:360-371).  d_sets[g] != nullptr: shard g's records are already resident on device g.
+static int verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const uint8_t* sets, const void* const d_sets[], size_t n, const uint8_t rnd[32]) {
+    if (!ctxs || ngpu == 0 || ngpu > 64 || !rnd || (!sets && !d_sets)) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    for (size_t g = 0; g < ngpu; g++)
+        if (!ctxs[g] || ctxs[g]->num_threads != ctxs[0]->num_threads) return MI355_BLS_ERR_ARG;
+    uint32_t nt = ctxs[0]->num_threads;
+    bool live[64] = {};
+    for (size_t g = 0; g < ngpu; g++) {
+        uint32_t lo, hi;
+        size_t first, count;
+        mi355_bls_shard_plan(n, nt, (uint32_t)ngpu, (uint32_t)g, &lo, &hi, &first, &count);
+        if (count == 0) continue;                                 // more devices than chunks
+        mi355_bls_ctx* c = ctxs[g];
+        if (count > c->cap) return MI355_BLS_ERR_CAPACITY;
+        HIPCHK(hipSetDevice(c->device));
+        const void* src = d_sets ? d_sets[g] : nullptr;
+        if (!src) {
+            if (!sets) return MI355_BLS_ERR_ARG;
+            HIPCHK(hipMemcpyAsync(c->d_sets, sets + 320 * first, count * 320, hipMemcpyHostToDevice, nullptr));
+            src = c->d_sets;
+        }
+        int rc = shard_enqueue(c, src, n, lo, hi, rnd, nullptr, nullptr);
+        if (rc) return rc;
+        live[g] = true;
+    }
+    std::vector<uint8_t> states;
+    bool all_ok = true;
+    int rc_keep = 0;
+    for (size_t g = 0; g < ngpu; g++) {
+        if (!live[g]) continue;
+        uint8_t st[576];
+        int ok = 0;
+        int rc = shard_wait(ctxs[g], st, &ok);                    // every enqueued shard is waited for, also after a failure
+        if (rc && !rc_keep) rc_keep = rc;
+        all_ok = all_ok && ok;
+        states.insert(states.end(), st, st + 576);
+    }
+    if (rc_keep) return rc_keep;
+    if (!all_ok) return 0;                                        // some update() failed (infinity public key)
+    return mi355_bls_finalverify_shards(ctxs[0], states.data(), states.size() / 576);
+}
+extern "C" int mi355_bls_batch_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* sets, size_t n, const uint8_t rnd[32]) {
+    if (n && !sets) return MI355_BLS_ERR_ARG;
+    return verify_multi(ctxs, ngpu, (const uint8_t*)sets, nullptr, n, rnd);
+}
+extern "C" int mi355_bls_batch_verify_multi_device(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* const d_sets[], size_t n, const uint8_t rnd[32]) {
+    if (n && !d_sets) return MI355_BLS_ERR_ARG;
+    return verify_multi(ctxs, ngpu, nullptr, d_sets, n, rnd);
+}
+
+// Process-wide default context for the entry points that take no context (the reference's cache-less overloads allocate a
+// cache per call, bls_batch_verifier.nim:399-416, :475-495; blst_p1s_mult_pippenger takes only a scratch pointer): created on
+// first use on HIP device $MI355_BLS_DEVICE (default 0), regrown when a call needs more capacity; calls are serialised.
+static std::mutex g_default_mu;
+static mi355_bls_ctx* g_default_ctx = nullptr;
+static int default_ctx_locked(size_t need_sets, mi355_bls_ctx** out) {
+    if (need_sets < 1024) need_sets = 1024;
+    if (g_default_ctx && g_default_ctx->cap >= need_sets) {
+        *out = g_default_ctx;
+        return 0;
+    }
+    if (g_default_ctx) {
+        mi355_bls_ctx_destroy(g_default_ctx);
+        g_default_ctx = nullptr;
+    }
+    const char* e = getenv("MI355_BLS_DEVICE");
+    int rc = mi355_bls_ctx_create(&g_default_ctx, e ? atoi(e) : 0, need_sets);
+    if (rc) return rc;
+    *out = g_default_ctx;
+    return 0;
+}
+extern "C" int mi355_bls_batch_verify_once(const void* sets, size_t n, const uint8_t rnd[32], uint32_t num_threads) {
+    if (!rnd || num_threads == 0) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!sets) return MI355_BLS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    mi355_bls_ctx* c;
+    int rc = default_ctx_locked(n, &c);
+    if (rc) return rc;
+    c->num_threads = num_threads;
+    // batchVerify's dispatch (bls_batch_verifier.nim:475-495): parallel iff numThreads > 1 and n >= 3
+    return verify_host(c, sets, n, rnd, (num_threads > 1 && n >= 3) ? 0 : 1);
+}
+extern "C" void mi355_bls_default_ctx_release(void) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default_ctx) mi355_bls_ctx_destroy(g_default_ctx);
+    g_default_ctx = nullptr;
 }
 
 extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size_t out_bytes) {
@@ -1899,7 +2061,7 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     k_lineprod<<<dim3(N_LINES, 1), WAVE, 0, st>>>(c->d_lines, 2, c->stride, 1, c->d_lpart, 1, 0);
     k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_lines, c->stride, 0xffffffffu, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1);
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     uint32_t fl[2];
     HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
@@ -1975,9 +2137,10 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
     return 0;
 }
 
-extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars,
-                                                   size_t nbits, void* stream) {
-    if (!c || !ret_p1 || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
+// sbytes: distance between scalars (32 for blst_scalar images; blst's own convention is (nbits + 7) / 8)
+static int msm_g1_run(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits,
+                      void* stream) {
+    if (!c || !ret_p1 || nbits == 0 || nbits > 256 || npoints > (1u << 28) || sbytes * 8 < nbits) return MI355_BLS_ERR_ARG;
     if (npoints == 0) {
         memset(ret_p1, 0, 144);
         return 0;
@@ -2000,9 +2163,9 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_msm_convert<<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
-    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, 32, n, W, cb, m->hist);
+    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, sbytes, n, W, cb, m->hist);
     k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
-    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, 32, n, W, cb, m->cursor, m->sorted);
+    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, sbytes, n, W, cb, m->cursor, m->sorted);
     uint32_t nbo = (total + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
     k_msm_order_hist<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist);
     k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
@@ -2021,6 +2184,10 @@ extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret
     HIPCHK(hipMemcpyAsync(ret_p1, m->out, 144, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return collect_timings(c, 4);       // [0] sort, [1] bucket accumulation, [2] segment reduction, [3] window sums + doublings
+}
+extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars,
+                                                   size_t nbits, void* stream) {
+    return msm_g1_run(c, ret_p1, d_points, npoints, d_scalars, 32, nbits, stream);
 }
 
 // Same shape as blst_p1s_mult_pippenger incl. the NULL-terminated pointer-to-array convention
@@ -2043,6 +2210,65 @@ extern "C" int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p1[144
     HIPCHK(hipMemcpyAsync(c->msm->d_pts, points[0], npoints * 96, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars[0], npoints * 32, hipMemcpyHostToDevice, nullptr));
     return mi355_bls_p1s_mult_pippenger_device(c, ret_p1, c->msm->d_pts, npoints, c->msm->d_sc, nbits, nullptr);
+}
+
+// blst's list convention (blst_p1s_mult_pippenger and friends): list[0] points at element 0; for every following element the
+// next list entry is used if it is non-NULL, otherwise the element follows the previous one in memory.  [ptr, NULL] is one
+// contiguous array (what the reference passes, benchmarks/bls12381_msm_g1.nim:52-55, core :613-616); npoints pointers
+// address every element individually.  Returns a contiguous view (gathered into tmp when needed).
+static const uint8_t* gather_list(const void* const list[], size_t n, size_t elem, std::vector<uint8_t>& tmp) {
+    const uint8_t* cur = (const uint8_t*)list[0];
+    if (n <= 1 || list[1] == nullptr) return cur;
+    tmp.resize(n * elem);
+    std::memcpy(tmp.data(), cur, elem);
+    size_t li = 1;
+    for (size_t i = 1; i < n; i++) {
+        if (list[li]) cur = (const uint8_t*)list[li++];
+        else cur += elem;
+        std::memcpy(tmp.data() + i * elem, cur, elem);
+    }
+    return tmp.data();
+}
+[[noreturn]] static void die_no_error_channel(const char* fn) {
+    std::fprintf(stderr, "%s: %s (this entry point has blst's void signature, so a runtime failure cannot be returned; aborting rather than "
+                 "handing back a wrong point)\n", fn, g_err.c_str());
+    std::abort();
+}
+
+// EXACTLY blst_p1s_mult_pippenger (blst+nim.h:70-72, blst_abi.nim:336-340): no context (the process-wide default one), void,
+// scalars (nbits + 7) / 8 bytes apart, scratch ignored (the workspace lives on the device).
+extern "C" size_t mi355_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
+    (void)npoints;
+    return 8;                       // never 0: callers malloc() it (benchmarks/bls12381_msm_g1.nim:50) and index scratch[0] (core :633)
+}
+extern "C" void mi355_p1s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch) {
+    (void)scratch;
+    if (!ret) return;
+    if (npoints == 0) {
+        std::memset(ret, 0, 144);
+        return;
+    }
+    if (!points || !points[0] || !scalars || !scalars[0] || nbits == 0 || nbits > 256) {
+        g_err = "bad arguments";
+        die_no_error_channel("mi355_p1s_mult_pippenger");
+    }
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    mi355_bls_ctx* c;
+    uint32_t sbytes = (uint32_t)((nbits + 7) / 8);
+    std::vector<uint8_t> tp, ts;
+    const uint8_t* P = gather_list(points, npoints, 96, tp);
+    const uint8_t* S = gather_list(reinterpret_cast<const void* const*>(scalars), npoints, sbytes, ts);
+    int rc = default_ctx_locked(1024, &c);
+    if (!rc) {
+        uint32_t c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
+        uint32_t cb = (uint32_t)nbits / nwin + (((uint32_t)nbits % nwin) ? 1 : 0);
+        if (cb < 4) cb = 4;
+        rc = msm_reserve(c, npoints, nwin, cb);
+    }
+    if (!rc && hipMemcpyAsync(c->msm->d_pts, P, npoints * 96, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = MI355_BLS_ERR_HIP, g_err = "H2D copy of the points";
+    if (!rc && hipMemcpyAsync(c->msm->d_sc, S, npoints * sbytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = MI355_BLS_ERR_HIP, g_err = "H2D copy of the scalars";
+    if (!rc) rc = msm_g1_run(c, (uint8_t*)ret, c->msm->d_pts, npoints, c->msm->d_sc, sbytes, nbits, nullptr);
+    if (rc) die_no_error_channel("mi355_p1s_mult_pippenger");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2252,7 +2478,7 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, np, c->stride, mm, c->d_lpart, nblk, 0);
     k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, 0xffffffffu, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1);
+    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipGetLastError());
     uint32_t fl[2];

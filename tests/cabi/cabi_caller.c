@@ -1,0 +1,74 @@
+/* A compiled (non-Python) caller of the C ABI: plain C, linked against libblscurve_mi355x.so, using only
+ * include/blscurve_mi355x.h - the way a Nim `importc` binding reaches the library.
+ * Reads tests/golden/cabi_fixture.bin (layout: tests/golden/gen_cabi_bin.py) and prints one line per check:
+ *   batchVerify(cache) / batchVerifySerial / cache-less batchVerify on the golden n17 batch      -> verdicts (expect 1)
+ *   the same on the golden forged_among_many batch                                                -> verdicts (expect 0)
+ *   blst_p1s_mult_pippenger-shaped MSM (n = 32): [ptr, NULL] lists and one-pointer-per-element lists -> blst_p1 hex
+ * The pytest wrapper (tests/test_gpu_cabi.py) compares the verdicts and canonicalises the points against the fixtures. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "blscurve_mi355x.h"
+
+static unsigned char* slurp(const char* path, size_t* len) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    *len = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char* b = (unsigned char*)malloc(*len);
+    if (fread(b, 1, *len, f) != *len) { perror("fread"); exit(2); }
+    fclose(f);
+    return b;
+}
+static unsigned rd32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24); }
+static void hex(const char* tag, const unsigned char* p, size_t n) {
+    printf("%s ", tag);
+    for (size_t i = 0; i < n; i++) printf("%02x", p[i]);
+    printf("\n");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s cabi_fixture.bin\n", argv[0]); return 2; }
+    size_t len;
+    unsigned char* f = slurp(argv[1], &len);
+    if (len < 12 || memcmp(f, "MI355CAB", 8)) { fprintf(stderr, "bad fixture\n"); return 2; }
+    const unsigned char* p = f + 8;
+    mi355_bls_ctx* ctx = NULL;
+    int rc = mi355_bls_ctx_create(&ctx, 0, 64);               /* BatchedBLSVerifierCache.init */
+    if (rc) { fprintf(stderr, "ctx_create: %d %s\n", rc, mi355_bls_last_error()); return 1; }
+    mi355_bls_ctx_set_num_threads(ctx, 4);                    /* Taskpool.new(numThreads = 4), tests/t_batch_verifier.nim:63 */
+    for (int k = 0; k < 2; k++) {
+        unsigned n = rd32(p);
+        const unsigned char* sets = p + 4;
+        const unsigned char* rnd = sets + 320 * (size_t)n;
+        p = rnd + 32;
+        printf("batch%d n %u\n", k, n);
+        printf("batch%d parallel %d\n", k, mi355_bls_batch_verify(ctx, sets, n, rnd));
+        printf("batch%d serial %d\n", k, mi355_bls_batch_verify_serial(ctx, sets, n, rnd));
+        printf("batch%d once %d\n", k, mi355_bls_batch_verify_once(sets, n, rnd, 4));
+    }
+    printf("empty %d\n", mi355_bls_batch_verify(ctx, f, 0, f + 8));
+    unsigned np = rd32(p), nbits = rd32(p + 4);
+    const unsigned char* pts = p + 8;
+    const unsigned char* sc = pts + 96 * (size_t)np;
+    unsigned char ret[144];
+    void* scratch = malloc(mi355_p1s_mult_pippenger_scratch_sizeof(np));      /* benchmarks/bls12381_msm_g1.nim:50 */
+    const void* pl[2] = {pts, NULL};                                           /* "Weird API with double indirection" (:53) */
+    const unsigned char* sl[2] = {sc, NULL};
+    mi355_p1s_mult_pippenger(ret, pl, np, sl, nbits, scratch);
+    hex("msm_contiguous", ret, 144);
+    const void** pe = (const void**)malloc(np * sizeof(void*));
+    const unsigned char** se = (const unsigned char**)malloc(np * sizeof(void*));
+    for (unsigned i = 0; i < np; i++) { pe[i] = pts + 96 * (size_t)i; se[i] = sc + 32 * (size_t)i; }
+    mi355_p1s_mult_pippenger(ret, pe, np, se, nbits, scratch);
+    hex("msm_pointer_list", ret, 144);
+    if (mi355_bls_p1s_mult_pippenger(ctx, ret, pl, np, sl, nbits)) { fprintf(stderr, "msm(ctx): %s\n", mi355_bls_last_error()); return 1; }
+    hex("msm_ctx", ret, 144);
+    free(scratch); free(pe); free(se);
+    mi355_bls_ctx_destroy(ctx);
+    mi355_bls_default_ctx_release();
+    free(f);
+    return 0;
+}

@@ -15,8 +15,8 @@ def m():
 
 def test_exports_match_header(m):
     hdr = open(m.HEADER_PATH).read()
-    names = set(re.findall(r"\b(mi355_bls_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 12
+    names = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 40 and "mi355_p1s_mult_pippenger" in names
     L = ctypes.CDLL(m.LIB_PATH)
     for n in names:
         assert hasattr(L, n), n
@@ -49,3 +49,20 @@ def test_no_gpu_fails_loudly(m):
         pytest.skip("GPU present")
     with pytest.raises(m.BlsGpuError):
         m.BatchedBLSVerifierCache.init(max_sets=16)
+
+
+def test_shard_plan_matches_python_plan(m):
+    """mi355_bls_shard_plan (what the in-library multi-GPU driver uses) == sharded.shard_plan (what the bench uses)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("sharded", os.path.join(os.path.dirname(m.LIB_PATH), "sharded.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    for n, t, w in [(17, 4, 2), (3, 4, 8), (1 << 20, 32768, 8), (1000, 64, 3), (5, 4096, 4), (1, 4, 2)]:
+        assert [m.shard_plan(n, t, w, g) for g in range(w)] == sh.shard_plan(n, t, w)
+
+
+def test_secure_random_bytes_must_be_32_bytes(m):
+    for bad in (bytes(31), bytes(33), 32, "x" * 32):
+        with pytest.raises(ValueError):
+            m._rnd32(bad)
+    assert m._rnd32(bytearray(32)) == bytes(32)

@@ -1,0 +1,36 @@
+"""The drop-in boundary exercised by a compiled, non-Python caller: tests/cabi/cabi_caller.c (plain C, only
+include/blscurve_mi355x.h) is built with gcc, linked against the in-tree library and run on the golden fixtures."""
+import os
+import subprocess
+
+import pytest
+
+import bls12381_py as o
+from util import g1_jac_to_affine, golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plain_c_caller(tmp_path):
+    import __graft_entry__ as ge
+    ge.build()
+    libdir = os.path.join(ROOT, "nim-blscurve_amd")
+    exe = str(tmp_path / "cabi_caller")
+    subprocess.check_call(["gcc", "-Wall", "-Wextra", "-std=c99", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi", "cabi_caller.c"), "-o", exe, "-L", libdir,
+                           "-l:libblscurve_mi355x.so", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "cabi_fixture.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    kv = {}
+    for line in out.stdout.splitlines():
+        k, v = line.rsplit(" ", 1)
+        kv[k] = v
+    # golden n17 verifies through every entry point, forged_among_many (t_batch_verifier.nim:198-244) through none
+    assert kv["batch0 n"] == "17" and kv["batch1 n"] == "18"
+    assert (kv["batch0 parallel"], kv["batch0 serial"], kv["batch0 once"]) == ("1", "1", "1")
+    assert (kv["batch1 parallel"], kv["batch1 serial"], kv["batch1 once"]) == ("0", "0", "0")
+    assert kv["empty"] == "0"
+    want = [v for v in golden("msm")["msm"] if v["n"] == 32][0]["result_affine"]
+    for k in ("msm_contiguous", "msm_pointer_list", "msm_ctx"):
+        assert o.g1_to_blst_affine(g1_jac_to_affine(bytes.fromhex(kv[k]))).hex() == want, k
