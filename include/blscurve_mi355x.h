@@ -107,6 +107,9 @@ int mi355_bls_finalverify_shards(mi355_bls_ctx* ctx, const uint8_t* fp12s, size_
  * (:670-672) on k blobs `stride_bytes` apart in DEVICE memory, enqueued on `stream`; finalverify_wait blocks and returns the
  * verdict (1 only if every shard's ok word is 1 and the product is one).  No host round trip between submit and verdict. */
 int mi355_bls_ctx_shard_blob_device(mi355_bls_ctx* ctx, void** d_blob);
+/* Redirect the blob to the caller's own device buffer (MI355_BLS_BLOB_BYTES, 16-byte aligned; e.g. the send buffer of the
+ * collective, so no copy is needed); NULL restores the context's internal buffer. */
+int mi355_bls_ctx_set_shard_blob_device(mi355_bls_ctx* ctx, void* d_blob);
 int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* ctx, const void* d_blobs, size_t k, size_t stride_bytes, void* stream);
 int mi355_bls_finalverify_wait(mi355_bls_ctx* ctx);
 
@@ -185,6 +188,22 @@ int mi355_bls_deserialize_sets(mi355_bls_ctx* ctx, const uint8_t* pks48, const u
                                void* out_sets, uint8_t* status);
 int mi355_bls_deserialize_sets_device(mi355_bls_ctx* ctx, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
                                       void* stream, void* out_sets, uint8_t* status);
+
+/* The other forms of fromBytes (bls_sig_io.nim:42-121), selected per side by `flags`:
+ *   MI355_BLS_DESER_PK_UNCOMPRESSED   keys are 96-byte images   -> blst_p1_deserialize (:88-91)
+ *   MI355_BLS_DESER_SIG_UNCOMPRESSED  signatures are 192-byte images -> blst_p2_deserialize (:49-52)
+ *   MI355_BLS_DESER_KNOWN_ON_CURVE    fromBytesKnownOnCurve (:60-79, :101-121): no subgroup checks (the infinity public key is
+ *                                     still rejected)
+ * blst_pN_deserialize [blst-upstream]: top bits of byte 0 = 000 uncompressed big-endian coordinates (G2: x.c1, x.c0, y.c1, y.c0),
+ * each < p, point on the curve; 1xx a compressed encoding in the first half; 01x infinity (0x40 followed by zeros only).
+ * pks: n x 48 or 96 bytes, sigs: n x 96 or 192 bytes; status codes and results as mi355_bls_deserialize_sets. */
+#define MI355_BLS_DESER_PK_UNCOMPRESSED 1u
+#define MI355_BLS_DESER_SIG_UNCOMPRESSED 2u
+#define MI355_BLS_DESER_KNOWN_ON_CURVE 4u
+int mi355_bls_deserialize_sets_ex(mi355_bls_ctx* ctx, const uint8_t* pks, const uint8_t* msgs32, const uint8_t* sigs, size_t n, uint32_t flags,
+                                  void* out_sets, uint8_t* status);
+int mi355_bls_deserialize_sets_ex_device(mi355_bls_ctx* ctx, const void* d_pks, const void* d_msgs32, const void* d_sigs, size_t n, uint32_t flags,
+                                         void* stream, void* out_sets, uint8_t* status);
 
 /* fromBytes for every tuple followed by batchVerify (bls_batch_verifier.nim:420-495), all on the device:
  * the wire format (176 B per tuple) is the only thing that crosses PCIe.  Returns 0 if any tuple fails to

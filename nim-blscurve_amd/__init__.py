@@ -61,6 +61,7 @@ def lib():
         L.mi355_bls_chunk_range.argtypes = [sz, u32, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mi355_bls_chunk_range.restype = None
         L.mi355_bls_ctx_shard_blob_device.argtypes = [vp, ctypes.POINTER(vp)]
+        L.mi355_bls_ctx_set_shard_blob_device.argtypes = [vp, vp]
         L.mi355_bls_finalverify_blobs_submit_device.argtypes = [vp, vp, sz, sz, vp]
         L.mi355_bls_finalverify_wait.argtypes = [vp]
         L.mi355_bls_shard_plan.argtypes = [sz, u32, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(sz), ctypes.POINTER(sz)]
@@ -84,6 +85,8 @@ def lib():
         cp = ctypes.c_char_p
         L.mi355_bls_deserialize_sets.argtypes = [vp, cp, cp, cp, sz, vp, vp]
         L.mi355_bls_deserialize_sets_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+        L.mi355_bls_deserialize_sets_ex.argtypes = [vp, cp, cp, cp, sz, u32, vp, vp]
+        L.mi355_bls_deserialize_sets_ex_device.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, vp]
         L.mi355_bls_batch_verify_compressed.argtypes = [vp, cp, cp, cp, sz, cp, vp]
         L.mi355_bls_batch_verify_compressed_device.argtypes = [vp, vp, vp, vp, sz, cp, vp, vp]
         L.mi355_bls_last_deser_ms.argtypes = [vp]
@@ -225,6 +228,10 @@ class BatchedBLSVerifierCache:
         p = ctypes.c_void_p()
         _check(lib().mi355_bls_ctx_shard_blob_device(self._h, ctypes.byref(p)))
         return p.value
+
+    def set_shard_blob_ptr(self, d_ptr):
+        """Shard submits write their blob (640 bytes) to this device address instead (the collective's send buffer); None resets."""
+        _check(lib().mi355_bls_ctx_set_shard_blob_device(self._h, d_ptr))
 
     def finalverify_blobs_submit(self, d_blobs, k, stride=640, stream=0):
         """merge + finalVerify on k gathered shard blobs resident in device memory; finalverify_wait() gives the verdict."""
@@ -389,6 +396,28 @@ def deserializeSets(cache, pubkeys, messages, signatures):
     out = ctypes.create_string_buffer(320 * n)
     st = ctypes.create_string_buffer(n)
     ok = _check(lib().mi355_bls_deserialize_sets(cache._h, pk, ms, sg, n, out, st))
+    return bool(ok), out.raw, st.raw
+
+
+DESER_PK_UNCOMPRESSED, DESER_SIG_UNCOMPRESSED, DESER_KNOWN_ON_CURVE = 1, 2, 4
+
+
+def deserializeSetsEx(cache, pubkeys, messages, signatures, pk_uncompressed=False, sig_uncompressed=False, known_on_curve=False):
+    """The other forms of fromBytes (bls_sig_io.nim:42-121): 96-byte keys / 192-byte signatures (blst_pN_deserialize) and
+    fromBytesKnownOnCurve (no subgroup checks).  -> (all_ok, records, status bytes)."""
+    pk = bytes(pubkeys) if isinstance(pubkeys, (bytes, bytearray, memoryview)) else b"".join(pubkeys)
+    ms = bytes(messages) if isinstance(messages, (bytes, bytearray, memoryview)) else b"".join(messages)
+    sg = bytes(signatures) if isinstance(signatures, (bytes, bytearray, memoryview)) else b"".join(signatures)
+    pkb, sgb = (96 if pk_uncompressed else 48), (192 if sig_uncompressed else 96)
+    n = len(ms) // 32
+    if len(ms) % 32 or len(pk) != pkb * n or len(sg) != sgb * n:
+        raise ValueError("n x %d-byte keys, n x 32-byte messages, n x %d-byte signatures" % (pkb, sgb))
+    if n == 0:
+        return True, b"", b""
+    flags = (DESER_PK_UNCOMPRESSED if pk_uncompressed else 0) | (DESER_SIG_UNCOMPRESSED if sig_uncompressed else 0) | (DESER_KNOWN_ON_CURVE if known_on_curve else 0)
+    out = ctypes.create_string_buffer(320 * n)
+    st = ctypes.create_string_buffer(n)
+    ok = _check(lib().mi355_bls_deserialize_sets_ex(cache._h, pk, ms, sg, n, flags, out, st))
     return bool(ok), out.raw, st.raw
 
 

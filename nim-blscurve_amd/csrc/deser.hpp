@@ -61,7 +61,7 @@ BLS_HDN bool g1_uncompress(g1_aff& out, bool& inf, const uint8_t* b) {
     inf = false;
     out = g1_aff{fp_zero(), fp_zero()};
     uint8_t f = b[0];
-    if (!(f & 0x80)) return false;                     // only the compressed form is accepted here
+    if (!(f & 0x80)) return false;                     // blst_p1_uncompress: the compressed bit must be set
     if (f & 0x40) {
         uint32_t any = f & 0x3f;
         for (int i = 1; i < 48; i++) any |= b[i];
@@ -128,14 +128,67 @@ BLS_HDN bool g2_in_subgroup(const g2_aff& q) {
     return fp2_eq(t.x, fp2_mul(ps.x, z2)) & fp2_eq(t.y, fp2_mul(ps.y, z3));
 }
 
-// One tuple: compressed (pk, sig) -> validated affine points.  Returns the deser_status.
-BLS_HD uint8_t deserialize_tuple(g1_aff& pk, g2_aff& sig, const uint8_t* pk48, const uint8_t* sig96) {
+// blst_p1_deserialize / blst_p2_deserialize (blst_abi.nim:394,400; used by fromBytes for 96- / 192-byte input,
+// bls_sig_io.nim:49-52,88-91) [blst-upstream semantics]: the three top bits of byte 0 select the form:
+//   000  uncompressed: big-endian x then y (G2: x.c1, x.c0, y.c1, y.c0), each < p, and the point must be on the curve;
+//   1xx  compressed: the first half is a compressed encoding (the rest is not read);
+//   01x  infinity: only valid as 0x40 followed by zeros;   anything else is a bad encoding.
+BLS_HDN bool g1_deserialize(g1_aff& out, bool& inf, const uint8_t* b) {
+    uint8_t f = b[0];
+    if (f & 0x80) return g1_uncompress(out, inf, b);
+    inf = false;
+    out = g1_aff{fp_zero(), fp_zero()};
+    if (f & 0x40) {
+        uint32_t any = f & 0x3f;
+        for (int i = 1; i < 96; i++) any |= b[i];
+        inf = true;
+        return any == 0;
+    }
+    if (f & 0x20) return false;
+    fp x, y;
+    if (!fp_from_be48(x, b, false) || !fp_from_be48(y, b + 48, false)) return false;
+    fp rhs = fp_add(fp_mul(fp_sqr(x), x), fp_from_const(k::B1));
+    if (!fp_eq(fp_sqr(y), rhs)) return false;                            // BLST_POINT_NOT_ON_CURVE
+    out = g1_aff{x, y};
+    return true;
+}
+BLS_HDN bool g2_deserialize(g2_aff& out, bool& inf, const uint8_t* b) {
+    uint8_t f = b[0];
+    if (f & 0x80) return g2_uncompress(out, inf, b);
+    inf = false;
+    out = g2_aff{fp2_zero(), fp2_zero()};
+    if (f & 0x40) {
+        uint32_t any = f & 0x3f;
+        for (int i = 1; i < 192; i++) any |= b[i];
+        inf = true;
+        return any == 0;
+    }
+    if (f & 0x20) return false;
+    fp2 x, y;
+    if (!fp_from_be48(x.c1, b, false) || !fp_from_be48(x.c0, b + 48, false)) return false;
+    if (!fp_from_be48(y.c1, b + 96, false) || !fp_from_be48(y.c0, b + 144, false)) return false;
+    fp2 b2{fp_from_const(k::B1), fp_from_const(k::B1)};                  // 4(1 + u)
+    fp2 rhs = fp2_add(fp2_mul(fp2_sqr(x), x), b2);
+    if (!fp2_eq(fp2_sqr(y), rhs)) return false;
+    out = g2_aff{x, y};
+    return true;
+}
+
+// flags of the general form (include/blscurve_mi355x.h): which wire form each side has, and fromBytesKnownOnCurve
+constexpr uint32_t DESER_F_PK_UNCOMPRESSED = 1, DESER_F_SIG_UNCOMPRESSED = 2, DESER_F_KNOWN_ON_CURVE = 4;
+
+// One tuple: wire-format (pk, sig) -> validated affine points.  Returns the deser_status.
+//   fromBytes (bls_sig_io.nim:42-58, 81-99): decode, "public key is not infinity", subgroup checks (infinity signature allowed)
+//   fromBytesKnownOnCurve (:60-79, 101-121): the same without the subgroup checks
+BLS_HD uint8_t deserialize_tuple(g1_aff& pk, g2_aff& sig, const uint8_t* pkb, const uint8_t* sigb, uint32_t flags) {
     bool inf;
-    if (!g1_uncompress(pk, inf, pk48)) return DESER_PK_BAD_ENCODING;
+    bool ok = (flags & DESER_F_PK_UNCOMPRESSED) ? g1_deserialize(pk, inf, pkb) : g1_uncompress(pk, inf, pkb);
+    if (!ok) return DESER_PK_BAD_ENCODING;
     if (inf) return DESER_PK_INFINITY;
-    if (!g1_in_subgroup(pk)) return DESER_PK_NOT_IN_G1;
-    if (!g2_uncompress(sig, inf, sig96)) return DESER_SIG_BAD_ENCODING;
-    if (!inf && !g2_in_subgroup(sig)) return DESER_SIG_NOT_IN_G2;
+    if (!(flags & DESER_F_KNOWN_ON_CURVE) && !g1_in_subgroup(pk)) return DESER_PK_NOT_IN_G1;
+    ok = (flags & DESER_F_SIG_UNCOMPRESSED) ? g2_deserialize(sig, inf, sigb) : g2_uncompress(sig, inf, sigb);
+    if (!ok) return DESER_SIG_BAD_ENCODING;
+    if (!(flags & DESER_F_KNOWN_ON_CURVE) && !inf && !g2_in_subgroup(sig)) return DESER_SIG_NOT_IN_G2;
     return DESER_OK;
 }
 

@@ -45,6 +45,10 @@
 #include <cstdlib>
 #include <execinfo.h>
 #define BLS_VB_FIELD uint32_t vb, lb;
+// multiply-add census of the host test build (tests/host_emu): every multiplier body adds its v_mad_i64_i32 count, so the
+// op-count model behind bench.py's roofline.int_mad is measured from the real formulas, not estimated
+namespace bls { inline unsigned long long g_mad_count = 0; }
+#define BLS_COUNT_MADS(n) (::bls::g_mad_count += (n))
 #define BLS_SET_VB(x, v) ((x).vb = (v))
 #define BLS_VB(x) ((x).vb)
 #define BLS_SET_LB(x, v) ((x).lb = (v))
@@ -60,6 +64,7 @@
     } while (0)
 #else
 #define BLS_VB_FIELD
+#define BLS_COUNT_MADS(n) ((void)0)
 #define BLS_SET_VB(x, v) ((void)0)
 #define BLS_VB(x) 0u
 #define BLS_SET_LB(x, v) ((void)0)
@@ -323,6 +328,7 @@ __host__ __device__ __noinline__ inline fp fp_mul(const fp& a, const fp& b) {
         BLS_REQUIRE(x > -LIM && x < LIM && y > -LIM && y < LIM, "fp_mul limb bound");
     }
 #endif
+    BLS_COUNT_MADS(392);
     return fp_mul_core(a, b);
 }
 __host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
@@ -334,6 +340,7 @@ __host__ __device__ __noinline__ inline fp fp_sqr(const fp& a) {
         BLS_REQUIRE(x > -(1ll << 29) - (1ll << 20) && x < (1ll << 29) + (1ll << 20), "fp_sqr limb bound");
     }
 #endif
+    BLS_COUNT_MADS(301);
     return fp_sqr_core(a);
 }
 __host__ __device__ inline fp fp_sqr_n(const fp& a, uint32_t n) {
@@ -351,6 +358,7 @@ __host__ __device__ __noinline__ inline fp fp_dot2(const fp& a, const fp& b, con
         BLS_REQUIRE(x > -LIM && x < LIM && y > -LIM && y < LIM && z > -LIM && z < LIM && w > -LIM && w < LIM, "fp_dot2 limb bound");
     }
 #endif
+    BLS_COUNT_MADS(588);
     return fp_dot2_core(a, b, c, d);
 }
 #endif

@@ -1142,12 +1142,14 @@ __global__ void __launch_bounds__(WAVE) k_sig_fold(const uint4* __restrict__ H, 
 // Signature.fromBytes per tuple (bls_sig_io.nim:42-58,81-99).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_deser(const uint8_t* __restrict__ pks, const uint8_t* __restrict__ msgs, const uint8_t* __restrict__ sigs,
-                                                uint32_t n, uint8_t* __restrict__ sets, uint8_t* __restrict__ status, uint32_t* __restrict__ flags) {
+                                                uint32_t n, uint32_t dflags, uint8_t* __restrict__ sets, uint8_t* __restrict__ status,
+                                                uint32_t* __restrict__ flags) {
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     if (i >= n) return;
     g1_aff pk;
     g2_aff sg;
-    uint8_t st = deserialize_tuple(pk, sg, pks + (size_t)i * 48, sigs + (size_t)i * 96);
+    const size_t pkb = (dflags & DESER_F_PK_UNCOMPRESSED) ? 96 : 48, sgb = (dflags & DESER_F_SIG_UNCOMPRESSED) ? 192 : 96;
+    uint8_t st = deserialize_tuple(pk, sg, pks + (size_t)i * pkb, sigs + (size_t)i * sgb, dflags);
     status[i] = st;
     if (st != DESER_OK) atomicOr(flags + 2, 1u);
     uint32_t* o = reinterpret_cast<uint32_t*>(sets + (size_t)i * 320);
@@ -1346,6 +1348,7 @@ struct mi355_bls_ctx {
     uint32_t* d_states = nullptr;    // up to 64 committed states (slot 0 = own)
     uint32_t* d_gt = nullptr;
     uint32_t* d_blob = nullptr;      // shard state + ok word for the device-resident exchange (MI355_BLS_BLOB_BYTES)
+    uint32_t* d_blob_out = nullptr;  // where shard submits write the blob: d_blob, or a caller's device buffer (set_shard_blob_device)
     bool fv_pending = false;         // a finalverify_blobs submit has not been waited for
     hipStream_t fv_stream = nullptr;
     uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
@@ -1433,13 +1436,14 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
     ALLOC(c->d_msg, 4096 + 192);
-    ALLOC(c->d_comp, max_sets * 176);
+    ALLOC(c->d_comp, max_sets * 320);          // wire-format staging: keys (<= 96 B) | messages (32 B) | signatures (<= 192 B)
     ALLOC(c->d_status, max_sets);
     ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * WAVE * F12W * 4);     // per-lane partial products of k_lineprod
     ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
     ALLOC(c->d_blob, MI355_BLS_BLOB_BYTES);
+    c->d_blob_out = c->d_blob;
     ALLOC(c->d_flags, 16);
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
@@ -1756,7 +1760,7 @@ static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, u
     }
     int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
     if (rc) return rc;
-    k_pack_blob<<<1, WAVE, 0, st>>>(c->d_states, c->d_flags, c->d_blob);
+    k_pack_blob<<<1, WAVE, 0, st>>>(c->d_states, c->d_flags, c->d_blob_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_flags + 16, c->d_states, 576, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4, hipMemcpyDeviceToHost, st));
@@ -1801,7 +1805,12 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
 
 extern "C" int mi355_bls_ctx_shard_blob_device(mi355_bls_ctx* c, void** d_blob) {
     if (!c || !d_blob) return MI355_BLS_ERR_ARG;
-    *d_blob = c->d_blob;
+    *d_blob = c->d_blob_out;
+    return 0;
+}
+extern "C" int mi355_bls_ctx_set_shard_blob_device(mi355_bls_ctx* c, void* d_blob) {
+    if (!c || ((uintptr_t)d_blob & 15)) return MI355_BLS_ERR_ARG;
+    c->d_blob_out = d_blob ? (uint32_t*)d_blob : c->d_blob;
     return 0;
 }
 
@@ -2274,23 +2283,24 @@ extern "C" void mi355_p1s_mult_pippenger(void* ret, const void* const points[], 
 // ------------------------------------------------------------------------------------------
 // Wire-format entry points: batched fromBytes (+ batchVerify)
 // ------------------------------------------------------------------------------------------
-static int deser_enqueue(mi355_bls_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint8_t* d_sigs, size_t n, hipStream_t st) {
+static int deser_enqueue(mi355_bls_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint8_t* d_sigs, size_t n, uint32_t dflags, hipStream_t st) {
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    if (dflags > 7) return MI355_BLS_ERR_ARG;
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
-    k_deser<<<((uint32_t)n + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_pks, d_msgs, d_sigs, (uint32_t)n, c->d_sets, c->d_status, c->d_flags);
+    k_deser<<<((uint32_t)n + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_pks, d_msgs, d_sigs, (uint32_t)n, dflags, c->d_sets, c->d_status, c->d_flags);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-extern "C" int mi355_bls_deserialize_sets_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n, void* stream,
-                                                 void* out_sets, uint8_t* status) {
+extern "C" int mi355_bls_deserialize_sets_ex_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n, uint32_t dflags,
+                                                    void* stream, void* out_sets, uint8_t* status) {
     if (!c) return MI355_BLS_ERR_ARG;
     if (n == 0) return 1;
     if (!d_pks48 || !d_msgs32 || !d_sigs96) return MI355_BLS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], st));
-    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, st);
+    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, dflags, st);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev[1], st));
     uint32_t fl[4];
@@ -2304,13 +2314,27 @@ extern "C" int mi355_bls_deserialize_sets_device(mi355_bls_ctx* c, const void* d
     return fl[2] ? 0 : 1;
 }
 
-static int stage_compressed(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n) {
+// host wire-format arrays -> d_comp: keys at 0, messages at cap * 96, signatures at cap * 128
+static int stage_compressed(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, uint32_t dflags) {
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->d_comp, pks, n * 48, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 48, msgs, n * 32, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 80, sigs, n * 96, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp, pks, n * ((dflags & DESER_F_PK_UNCOMPRESSED) ? 96 : 48), hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 96, msgs, n * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 128, sigs, n * ((dflags & DESER_F_SIG_UNCOMPRESSED) ? 192 : 96), hipMemcpyHostToDevice, nullptr));
     return 0;
+}
+extern "C" int mi355_bls_deserialize_sets_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n, void* stream,
+                                                 void* out_sets, uint8_t* status) {
+    return mi355_bls_deserialize_sets_ex_device(c, d_pks48, d_msgs32, d_sigs96, n, 0, stream, out_sets, status);
+}
+extern "C" int mi355_bls_deserialize_sets_ex(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs32, const uint8_t* sigs, size_t n, uint32_t dflags,
+                                             void* out_sets, uint8_t* status) {
+    if (!c || dflags > 7) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 1;
+    if (!pks || !msgs32 || !sigs) return MI355_BLS_ERR_ARG;
+    int rc = stage_compressed(c, pks, msgs32, sigs, n, dflags);
+    if (rc) return rc;
+    return mi355_bls_deserialize_sets_ex_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, dflags, nullptr, out_sets, status);
 }
 
 extern "C" int mi355_bls_deserialize_sets(mi355_bls_ctx* c, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n, void* out_sets,
@@ -2318,9 +2342,9 @@ extern "C" int mi355_bls_deserialize_sets(mi355_bls_ctx* c, const uint8_t* pks48
     if (!c) return MI355_BLS_ERR_ARG;
     if (n == 0) return 1;
     if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
-    int rc = stage_compressed(c, pks48, msgs32, sigs96, n);
+    int rc = stage_compressed(c, pks48, msgs32, sigs96, n, 0);
     if (rc) return rc;
-    return mi355_bls_deserialize_sets_device(c, c->d_comp, c->d_comp + c->cap * 48, c->d_comp + c->cap * 80, n, nullptr, out_sets, status);
+    return mi355_bls_deserialize_sets_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, nullptr, out_sets, status);
 }
 
 extern "C" int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
@@ -2331,7 +2355,7 @@ extern "C" int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* c, const 
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev_deser0, st));
-    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, st);
+    int rc = deser_enqueue(c, (const uint8_t*)d_pks48, (const uint8_t*)d_msgs32, (const uint8_t*)d_sigs96, n, 0, st);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_deser1, st));
     uint32_t fl[4];
@@ -2348,9 +2372,9 @@ extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t
     if (!c || !rnd) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;
     if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
-    int rc = stage_compressed(c, pks48, msgs32, sigs96, n);
+    int rc = stage_compressed(c, pks48, msgs32, sigs96, n, 0);
     if (rc) return rc;
-    return mi355_bls_batch_verify_compressed_device(c, c->d_comp, c->d_comp + c->cap * 48, c->d_comp + c->cap * 80, n, rnd, nullptr, status);
+    return mi355_bls_batch_verify_compressed_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, rnd, nullptr, status);
 }
 
 extern "C" float mi355_bls_last_deser_ms(mi355_bls_ctx* c) { return c ? c->deser_ms : 0.f; }

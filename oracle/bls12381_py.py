@@ -463,6 +463,62 @@ def g2_decompress(b):
     return (x, y)
 
 
+def g1_serialize(p):
+    """Uncompressed 96-byte form (blst_p1_affine_serialize; `serialize` into array[96, byte], bls_sig_io.nim:194-245)."""
+    if p is None:
+        return bytes([0x40]) + bytes(95)
+    return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+
+
+def g1_deserialize(b):
+    """blst_p1_deserialize semantics (bls_sig_io.nim:88-91 for 96-byte input): top bits 000 uncompressed, 1xx compressed
+    (first 48 bytes), 01x infinity (0x40 then zeros only)."""
+    if len(b) != 96:
+        raise ValueError("length")
+    if b[0] & 0x80:
+        return g1_decompress(b[:48])
+    if b[0] & 0x40:
+        if b[0] & 0x3f or any(b[1:]):
+            raise ValueError("bad infinity")
+        return None
+    if b[0] & 0x20:
+        raise ValueError("bad encoding")
+    x, y = int.from_bytes(b[:48], "big"), int.from_bytes(b[48:], "big")
+    if x >= P or y >= P:
+        raise ValueError("coordinate >= p")
+    if not g1_on_curve((x, y)):
+        raise ValueError("not on curve")
+    return (x, y)
+
+
+def g2_serialize(p):
+    if p is None:
+        return bytes([0x40]) + bytes(191)
+    (x0, x1), (y0, y1) = p
+    return x1.to_bytes(48, "big") + x0.to_bytes(48, "big") + y1.to_bytes(48, "big") + y0.to_bytes(48, "big")
+
+
+def g2_deserialize(b):
+    """blst_p2_deserialize semantics (bls_sig_io.nim:49-52 for 192-byte input)."""
+    if len(b) != 192:
+        raise ValueError("length")
+    if b[0] & 0x80:
+        return g2_decompress(b[:96])
+    if b[0] & 0x40:
+        if b[0] & 0x3f or any(b[1:]):
+            raise ValueError("bad infinity")
+        return None
+    if b[0] & 0x20:
+        raise ValueError("bad encoding")
+    x1, x0, y1, y0 = (int.from_bytes(b[48 * i:48 * i + 48], "big") for i in range(4))
+    if max(x0, x1, y0, y1) >= P:
+        raise ValueError("coordinate >= p")
+    q = ((x0, x1), (y0, y1))
+    if not g2_on_curve(q):
+        raise ValueError("not on curve")
+    return q
+
+
 # blst in-memory layouts (blst_abi.nim:87-122): Montgomery limbs, little-endian
 def fp_to_mont_bytes(a):
     return (a * MONT_R % P).to_bytes(48, "little")

@@ -574,18 +574,44 @@ static int g2_uncompress(g2a* out, const uint8_t* b) {
     if (large != ((b[0] >> 5) & 1)) y = f2_neg(&y);
     out->x = x; out->y = y; return 0;
 }
-/* status bytes as in include/blscurve_mi355x.h; out320 may be NULL.  Returns 1 when every tuple deserialised. */
-int oracle_deserialize_sets(const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, uint8_t* out320, uint8_t* status) {
+/* blst_p1_deserialize / blst_p2_deserialize semantics for the 96- / 192-byte forms: 000 uncompressed (big-endian coordinates
+ * < p, on the curve), 1xx compressed, 01x infinity (0x40 then zeros), else bad.  0 ok, 1 bad. */
+static int g1_deserialize(g1a* out, const uint8_t* b) {
+    if (b[0] & 0x80) return g1_uncompress(out, b);
+    memset(out, 0, sizeof *out);
+    if (b[0] & 0x40) { int any = b[0] & 0x3f; for (int i = 1; i < 96; i++) any |= b[i]; out->inf = 1; return any != 0; }
+    if (b[0] & 0x20) return 1;
+    fp x, y; if (!fp_from_be48(&x, b, 0) || !fp_from_be48(&y, b + 48, 0)) return 1;
+    fp x2 = fp_sqr(&x), x3 = fp_mul(&x2, &x), four = fp_small(4), rhs = fp_add(&x3, &four), y2 = fp_sqr(&y);
+    if (!fp_eq(&y2, &rhs)) return 1;
+    out->x = x; out->y = y; return 0;
+}
+static int g2_deserialize(g2a* out, const uint8_t* b) {
+    if (b[0] & 0x80) return g2_uncompress(out, b);
+    memset(out, 0, sizeof *out);
+    if (b[0] & 0x40) { int any = b[0] & 0x3f; for (int i = 1; i < 192; i++) any |= b[i]; out->inf = 1; return any != 0; }
+    if (b[0] & 0x20) return 1;
+    fp2 x, y;
+    if (!fp_from_be48(&x.c1, b, 0) || !fp_from_be48(&x.c0, b + 48, 0) || !fp_from_be48(&y.c1, b + 96, 0) || !fp_from_be48(&y.c0, b + 144, 0)) return 1;
+    fp2 x2 = f2_sqr(&x), x3 = f2_mul(&x2, &x), b2; b2.c0 = fp_small(4); b2.c1 = fp_small(4);
+    fp2 rhs = f2_add(&x3, &b2), y2 = f2_sqr(&y);
+    if (!f2_eq(&y2, &rhs)) return 1;
+    out->x = x; out->y = y; return 0;
+}
+/* status bytes and flags as in include/blscurve_mi355x.h (1: 96-byte keys, 2: 192-byte signatures, 4: KnownOnCurve = no subgroup
+ * checks); out320 may be NULL.  Returns 1 when every tuple deserialised. */
+int oracle_deserialize_sets_ex(const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, unsigned flags, uint8_t* out320, uint8_t* status) {
     int all = 1;
+    size_t pkb = (flags & 1) ? 96 : 48, sgb = (flags & 2) ? 192 : 96;
 #pragma omp parallel for schedule(dynamic, 8) reduction(& : all)
     for (long i = 0; i < (long)n; i++) {
         g1a pk; g2a sg; uint8_t st = 0;
-        if (g1_uncompress(&pk, pks + 48 * i)) st = 1;
+        if ((flags & 1) ? g1_deserialize(&pk, pks + pkb * i) : g1_uncompress(&pk, pks + pkb * i)) st = 1;
         else if (pk.inf) st = 3;
-        else { g1j pj = g1_from_aff(&pk), t = g1_mul(&pj, K_R_LE, 255); if (!g1_is_inf(&t)) st = 2; }
+        else if (!(flags & 4)) { g1j pj = g1_from_aff(&pk), t = g1_mul(&pj, K_R_LE, 255); if (!g1_is_inf(&t)) st = 2; }
         if (!st) {
-            if (g2_uncompress(&sg, sigs + 96 * i)) st = 4;
-            else if (!sg.inf) { g2j sj = g2_from_aff(&sg), t = g2_mul(&sj, K_R_LE, 255); if (!g2_is_inf(&t)) st = 5; }
+            if ((flags & 2) ? g2_deserialize(&sg, sigs + sgb * i) : g2_uncompress(&sg, sigs + sgb * i)) st = 4;
+            else if (!sg.inf && !(flags & 4)) { g2j sj = g2_from_aff(&sg), t = g2_mul(&sj, K_R_LE, 255); if (!g2_is_inf(&t)) st = 5; }
         }
         if (status) status[i] = st;
         if (st) all = 0;
@@ -597,6 +623,22 @@ int oracle_deserialize_sets(const uint8_t* pks, const uint8_t* msgs, const uint8
         }
     }
     return all;
+}
+int oracle_deserialize_sets(const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, uint8_t* out320, uint8_t* status) {
+    return oracle_deserialize_sets_ex(pks, msgs, sigs, n, 0, out320, status);
+}
+/* uncompressed serialisation of the 320-byte records (96-byte keys, 192-byte signatures; infinity = 0x40 then zeros) */
+void oracle_serialize_sets(const uint8_t* sets, size_t n, uint8_t* pks96, uint8_t* sigs192) {
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* r = sets + 320 * i;
+        g1a pk = ld_g1a(r); g2a sg = ld_g2a(r + 128);
+        uint8_t* o = pks96 + 96 * i; memset(o, 0, 96);
+        if (pk.inf) o[0] = 0x40;
+        else { fp c[2] = {fp_from_mont(&pk.x), fp_from_mont(&pk.y)}; for (int q = 0; q < 2; q++) for (int k = 0; k < 6; k++) for (int j = 0; j < 8; j++) o[48 * q + 40 - 8 * k + j] = (uint8_t)(c[q].l[k] >> (56 - 8 * j)); }
+        o = sigs192 + 192 * i; memset(o, 0, 192);
+        if (sg.inf) o[0] = 0x40;
+        else { fp c[4] = {fp_from_mont(&sg.x.c1), fp_from_mont(&sg.x.c0), fp_from_mont(&sg.y.c1), fp_from_mont(&sg.y.c0)}; for (int q = 0; q < 4; q++) for (int k = 0; k < 6; k++) for (int j = 0; j < 8; j++) o[48 * q + 40 - 8 * k + j] = (uint8_t)(c[q].l[k] >> (56 - 8 * j)); }
+    }
 }
 /* ZCash compression of the 320-byte records (for building wire-format test inputs) */
 void oracle_compress_sets(const uint8_t* sets, size_t n, uint8_t* pks48, uint8_t* msgs32, uint8_t* sigs96) {
@@ -648,10 +690,59 @@ void oracle_msm_g1(const uint8_t* pts, const uint8_t* scalars, size_t n, int nbi
     }
     g1a r = g1_to_aff(&acc); st_g1a(out96, &r);
 }
+/* Pippenger bucket method (the published algorithm blst_p1s_mult_pippenger implements; restated, not copied: BLST's source is
+ * absent): the nbits are cut into windows of c bits; per window every point is added into the bucket of its digit, the buckets are
+ * integrated with a running sum (sum_d d * B_d), and the window results are combined by c doublings each.  Windows run on
+ * OpenMP threads.  Same semantics as oracle_msm_g1 (scalars taken mod 2^nbits, 32-byte little-endian). */
+static uint32_t msm_digit(const uint8_t* k, int bit0, int c, int nbits) {
+    uint32_t d = 0;
+    for (int j = 0; j < c && bit0 + j < nbits; j++) d |= (uint32_t)((k[(bit0 + j) >> 3] >> ((bit0 + j) & 7)) & 1) << j;
+    return d;
+}
+void oracle_msm_g1_pippenger(const uint8_t* pts, const uint8_t* scalars, size_t n, int nbits, uint8_t out96[96]) {
+    int c = 1;
+    while (c < 16 && ((size_t)1 << (c + 3)) <= n) c++;          /* about log2(n) - 2 */
+    int nwin = (nbits + c - 1) / c;
+    g1j* win = (g1j*)malloc((size_t)nwin * sizeof(g1j));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int w = 0; w < nwin; w++) {
+        size_t nb = (size_t)1 << c;
+        g1j* B = (g1j*)malloc(nb * sizeof(g1j));
+        for (size_t b = 0; b < nb; b++) B[b] = g1_inf();
+        for (size_t i = 0; i < n; i++) {
+            uint32_t d = msm_digit(scalars + 32 * i, w * c, c, nbits);
+            if (!d) continue;
+            g1a a = ld_g1a(pts + 96 * i); g1j j = g1_from_aff(&a);
+            B[d] = g1_add(&B[d], &j);
+        }
+        g1j run = g1_inf(), acc = g1_inf();
+        for (size_t b = nb - 1; b >= 1; b--) { run = g1_add(&run, &B[b]); acc = g1_add(&acc, &run); }
+        win[w] = acc;
+        free(B);
+    }
+    g1j acc = g1_inf();
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int j = 0; j < c; j++) acc = g1_dbl(&acc);
+        acc = g1_add(&acc, &win[w]);
+    }
+    free(win);
+    g1a r = g1_to_aff(&acc); st_g1a(out96, &r);
+}
+/* coreVerify (blst_min_pubkey_sig_core.nim:269-297; `verify`, bls_sig_min_pubkey.nim:100-107): e(pk, H(msg)) == e(G1, sig) */
+int oracle_core_verify(const uint8_t pk96[96], const uint8_t* msg, size_t mlen, const uint8_t sig192[192]) {
+    return oracle_fast_aggregate_verify(pk96, 1, msg, mlen, sig192);
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
 #endif
 }

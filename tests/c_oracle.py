@@ -22,10 +22,16 @@ def lib():
         L.oracle_make_pks.argtypes = [vp, sz, ctypes.c_uint64]
         L.oracle_deserialize_sets.argtypes = [cp, cp, cp, sz, vp, vp]
         L.oracle_compress_sets.argtypes = [cp, sz, vp, vp, vp]
+        L.oracle_deserialize_sets_ex.argtypes = [cp, cp, cp, sz, ctypes.c_uint, vp, vp]
+        L.oracle_serialize_sets.argtypes = [cp, sz, vp, vp]
         L.oracle_g1_sum.argtypes = [cp, sz, cp]
         L.oracle_fast_aggregate_verify.argtypes = [cp, sz, cp, sz, cp]
         L.oracle_msm_g1.argtypes = [cp, cp, sz, i32, cp]
         L.oracle_sha256.argtypes = [cp, sz, cp]
+        L.oracle_msm_g1_pippenger.argtypes = [cp, cp, sz, i32, cp]
+        L.oracle_core_verify.argtypes = [cp, cp, sz, cp]
+        L.oracle_set_num_threads.argtypes = [i32]
+        L.oracle_set_num_threads.restype = None
         _lib = L
     return _lib
 
@@ -89,6 +95,20 @@ def msm_g1(pts, scalars, nbits=255):
     return o.raw
 
 
+def msm_g1_pippenger(pts, scalars, nbits=255):
+    o = ctypes.create_string_buffer(96)
+    lib().oracle_msm_g1_pippenger(pts, scalars, len(pts) // 96, nbits, o)
+    return o.raw
+
+
+def core_verify(pk, msg, sig):
+    return bool(lib().oracle_core_verify(pk, msg, len(msg), sig))
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(n)
+
+
 def make_pks(n, seed=0):
     """(pks, sum of the secret keys mod r) for the keys oracle_make_batch derives."""
     import hashlib
@@ -115,4 +135,19 @@ def deserialize_sets(pks, msgs, sigs):
     n = len(pks) // 48
     out, st = ctypes.create_string_buffer(320 * n), ctypes.create_string_buffer(n)
     ok = lib().oracle_deserialize_sets(pks, msgs, sigs, n, out, st)
+    return bool(ok), out.raw, st.raw
+
+
+def serialize_sets(sets):
+    """Uncompressed wire form of the records: (n x 96-byte keys, n x 192-byte signatures)."""
+    n = len(sets) // 320
+    pk, sg = ctypes.create_string_buffer(96 * n), ctypes.create_string_buffer(192 * n)
+    lib().oracle_serialize_sets(sets, n, pk, sg)
+    return pk.raw, sg.raw
+
+
+def deserialize_sets_ex(pks, msgs, sigs, flags):
+    n = len(msgs) // 32
+    out, st = ctypes.create_string_buffer(320 * n), ctypes.create_string_buffer(n)
+    ok = lib().oracle_deserialize_sets_ex(pks, msgs, sigs, n, flags, out, st)
     return bool(ok), out.raw, st.raw

@@ -70,9 +70,49 @@ int emu_g2_uncompress(const uint8_t* b96, uint8_t* out192, int* inf) {
     g2_aff a; bool i; bool ok = g2_uncompress(a, i, b96); *inf = i;
     fp2_store_le(out192, a.x); fp2_store_le(out192 + 96, a.y); return ok;
 }
+// 96- / 192-byte forms (blst_pN_deserialize semantics)
+int emu_g1_deserialize(const uint8_t* b96, uint8_t* out96, int* inf) {
+    g1_aff a; bool i; bool ok = g1_deserialize(a, i, b96); *inf = i;
+    fp_store_le(out96, a.x); fp_store_le(out96 + 48, a.y); return ok;
+}
+int emu_g2_deserialize(const uint8_t* b192, uint8_t* out192, int* inf) {
+    g2_aff a; bool i; bool ok = g2_deserialize(a, i, b192); *inf = i;
+    fp2_store_le(out192, a.x); fp2_store_le(out192 + 96, a.y); return ok;
+}
+int emu_deserialize_tuple_ex(const uint8_t* pk, const uint8_t* sig, uint32_t flags) { g1_aff p; g2_aff s; return deserialize_tuple(p, s, pk, sig, flags); }
 int emu_g1_in_subgroup(const uint8_t* aff96) { return g1_in_subgroup(g1_aff_load(aff96)); }
 int emu_g2_in_subgroup(const uint8_t* aff192) { return g2_in_subgroup(g2_aff_load(aff192)); }
-int emu_deserialize_tuple(const uint8_t* pk48, const uint8_t* sig96) { g1_aff p; g2_aff s; return deserialize_tuple(p, s, pk48, sig96); }
+int emu_deserialize_tuple(const uint8_t* pk48, const uint8_t* sig96) { g1_aff p; g2_aff s; return deserialize_tuple(p, s, pk48, sig96, 0); }
 void emu_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp12_store_le(r, fp12_mul(fp12_load_le(a), fp12_load_le(b))); }
 void emu_final_exp(const uint8_t* a, uint8_t* r) { fp12_store_le(r, final_exp(fp12_load_le(a))); }
+// Multiply-add census of ONE tuple through each stage of the one-lane-per-item pipeline (the formulas the kernels run):
+//   0 k_hash_map (hash_to_field + 2 x SSWU + isogeny)   1 k_hash_clear (add + cofactor clearing)   2 k_pkmul (load + [r]PK)
+//   3 signature side (convert + 8 bucket additions)     4 k_lines (68 lines)                       5 k_lineprod (68 sparse products)
+unsigned long long emu_mad_census(int stage, const uint8_t* set320, uint64_t r) {
+#if defined(BLS_TRACK_BOUNDS)
+    const uint8_t dst[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";
+    fp2 u0, u1;
+    hash_to_field_fp2x2(u0, u1, set320 + 96, 32, dst, sizeof(dst) - 1);
+    g2_jac q0 = iso3_g2(sswu_g2(u0)), q1 = iso3_g2(sswu_g2(u1));
+    g2_jac h = clear_cofactor_g2(jac_add(q0, q1));
+    g1_aff pk = g1_aff_load(set320);
+    g2_aff sg = g2_aff_load(set320 + 128);
+    g1_jac rp = jac_mul_u64_w4(pk, r);
+    line_t L[N_LINES];
+    miller_lines(rp, h, [&](int s, const line_t& l) { L[s] = l; });
+    g_mad_count = 0;
+    switch (stage) {
+        case 0: hash_to_field_fp2x2(u0, u1, set320 + 96, 32, dst, sizeof(dst) - 1); (void)iso3_g2(sswu_g2(u0)); (void)iso3_g2(sswu_g2(u1)); break;
+        case 1: (void)clear_cofactor_g2(jac_add(q0, q1)); break;
+        case 2: (void)jac_mul_u64_w4(g1_aff_load(set320), r); break;
+        case 3: { g2_aff s2 = g2_aff_load(set320 + 128); g2_jac acc = jac_from_aff(sg); acc = jac_dbl(acc); for (int i = 0; i < 8; i++) acc = jac_add_aff(acc, s2); } break;
+        case 4: miller_lines(rp, h, [&](int, const line_t&) {}); break;
+        case 5: { fp12 f = fp12_from_line(L[0]); for (int s = 0; s < N_LINES; s++) f = fp12_mul_by_line(f, L[s]); } break;
+    }
+    return g_mad_count;
+#else
+    (void)stage; (void)set320; (void)r;
+    return 0;
+#endif
+}
 }

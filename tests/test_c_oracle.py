@@ -85,3 +85,26 @@ def test_compress_deserialize_roundtrip_and_python_parity():
     assert not ok and st == bytes([3])
     ok, out, st = co.deserialize_sets(pk[:48], ms[:32], bytes([0xc0]) + bytes(95))
     assert ok and st == bytes([0]) and out[128:] == bytes(192)
+
+
+def test_pippenger_restatement_equals_naive_msm():
+    """oracle_msm_g1_pippenger (CPU baseline of the MSM bench row) == the naive per-point multiplication == golden."""
+    import random
+    for v in golden("msm")["msm"]:
+        pts, sc = bytes.fromhex(v["points"]), bytes.fromhex(v["scalars"])
+        assert co.msm_g1_pippenger(pts, sc, v["nbits"]) == co.msm_g1(pts, sc, v["nbits"])
+        assert co.msm_g1_pippenger(pts, sc, v["nbits"]).hex() == v["result_affine"]
+    v = golden("msm")["msm"][-1]
+    pts, sc = bytes.fromhex(v["points"]), bytes.fromhex(v["scalars"])
+    rng = random.Random(3)
+    big = b"".join(pts[96 * rng.randrange(v["n"]):][:96] for _ in range(3000))
+    bsc = bytes(rng.getrandbits(8) for _ in range(32 * 3000))
+    for nbits in (255, 64, 9):
+        assert co.msm_g1_pippenger(big, bsc, nbits) == co.msm_g1(big, bsc, nbits)
+
+
+def test_core_verify():
+    sk = 0x1234567
+    pk, msg = co.sk_to_pk(sk), b"Mr F was here"
+    sig = co.sign(sk, msg)
+    assert co.core_verify(pk, msg, sig) and not co.core_verify(pk, msg + b"!", sig)

@@ -128,3 +128,112 @@ def test_scale_vs_c_oracle(m, cache):
     sgc[0:96], sgc[96:192] = sg[96:192], sg[0:96]
     v, st3 = m.batchVerifyCompressed(cache, pk, ms, bytes(sgc), rnd)
     assert v is False and st3 == bytes(n)
+
+
+# ---- the other forms of fromBytes: 96- / 192-byte images (blst_pN_deserialize) and fromBytesKnownOnCurve ----
+
+def test_serialization_roundtrip_all_forms(m, cache):
+    """The shape of tests/serialization.nim:52-142: keys of the secret keys 1000..1004, signatures over the hash-to-curve
+    spec messages; serialize -> fromBytes gives the same point, for the compressed AND the uncompressed form of each side
+    (the reference's uncompressed half is commented out, :97-109; its entry points exist, bls_sig_io.nim:49-52,88-91)."""
+    import c_oracle as co
+    msgs = [b"", b"abc", b"abcdef0123456789", b"q128_" + b"q" * 128, b"a512_" + b"a" * 512]
+    sets, m32 = [], []
+    for sk in range(1000, 1005):
+        pk = co.sk_to_pk(sk)
+        for msg in msgs:
+            d = o.sha256(msg)                                   # SignatureSet messages are 32-byte digests (bls_batch_verifier.nim:42)
+            sets.append(pk + d + co.sign(sk, d))
+            m32.append(d)
+    rec = b"".join(sets)
+    n = len(sets)
+    pk48, ms, sg96 = co.compress_sets(rec)
+    pk96, sg192 = co.serialize_sets(rec)
+    for i in (0, 7):                                            # the C serialiser against the KAT-pinned python one
+        assert pk96[96 * i:96 * i + 96] == o.g1_serialize(o.g1_from_blst_affine(rec[320 * i:320 * i + 96]))
+        assert sg192[192 * i:192 * i + 192] == o.g2_serialize(o.g2_from_blst_affine(rec[320 * i + 128:320 * i + 320]))
+    for pku, sgu in ((False, False), (True, False), (False, True), (True, True)):
+        for known in (False, True):
+            ok, out, st = m.deserializeSetsEx(cache, pk96 if pku else pk48, ms, sg192 if sgu else sg96, pk_uncompressed=pku, sig_uncompressed=sgu,
+                                              known_on_curve=known)
+            assert ok and st == bytes(n) and out == rec, (pku, sgu, known)
+    # blst_pN_deserialize also takes a COMPRESSED encoding in its first half (top bit set)
+    pk_mixed = b"".join(pk48[48 * i:48 * i + 48] + bytes(48) if i % 2 else pk96[96 * i:96 * i + 96] for i in range(n))
+    sg_mixed = b"".join(sg96[96 * i:96 * i + 96] + bytes(96) if i % 3 else sg192[192 * i:192 * i + 192] for i in range(n))
+    ok, out, st = m.deserializeSetsEx(cache, pk_mixed, ms, sg_mixed, pk_uncompressed=True, sig_uncompressed=True)
+    assert ok and out == rec
+
+
+def test_uncompressed_rejections_match_the_oracles(m, cache):
+    """Per-tuple statuses of the 96- / 192-byte forms against the C restatement and the big-int oracle: off-curve points,
+    coordinates >= p, flag-bit misuse, infinity encodings (good and bad), points outside the subgroups (rejected by
+    fromBytes, accepted by fromBytesKnownOnCurve), the reference's BAD_SIG bytes (tests/serialization.nim:39-45)."""
+    import c_oracle as co
+    rng = random.Random(77)
+    base = co.make_batch(4, seed=9)
+    gpk96, gsg192 = co.serialize_sets(base)
+    good_pk, good_sg = gpk96[:96], gsg192[:192]
+    p_off = _curve_point_g1(rng)                                 # on the curve, (almost surely) not in G1
+    q_off = _curve_point_g2(rng)
+    P = o.P
+    cases = []                                                   # (pk96, sig192)
+    cases.append((good_pk, good_sg))
+    cases.append((o.g1_serialize(p_off), good_sg))               # pk not in G1
+    cases.append((good_pk, o.g2_serialize(q_off)))               # sig not in G2
+    bad_y = bytearray(good_pk); bad_y[95] ^= 1
+    cases.append((bytes(bad_y), good_sg))                        # off the curve
+    cases.append((P.to_bytes(48, "big") + good_pk[48:], good_sg))              # x = p: top bits 000 but >= p
+    cases.append((good_pk[:48] + (P + 1).to_bytes(48, "big"), good_sg))        # y >= p
+    cases.append((bytes([0x40]) + bytes(95), good_sg))           # infinity public key: decodes, then rejected (status 3)
+    cases.append((bytes([0x40]) + bytes(94) + b"\x01", good_sg))                # bad infinity
+    cases.append((bytes([0x20 | good_pk[0]]) + good_pk[1:], good_sg))          # sign flag without the compressed bit
+    cases.append((good_pk, bytes([0x40]) + bytes(191)))          # infinity signature: allowed
+    cases.append((good_pk, bytes([0x40]) + bytes(100) + b"\x02" + bytes(90)))  # bad infinity signature
+    bad_sy = bytearray(good_sg); bad_sy[191] ^= 4
+    cases.append((good_pk, bytes(bad_sy)))                       # signature off the curve
+    cases.append((good_pk, good_sg[:96] + P.to_bytes(48, "big") + good_sg[144:]))   # y.c1 = p
+    cases.append((good_pk, BAD_SIG + bytes(96)))                 # compressed-form bytes of the reference's hardening test
+    cases.append((bytes(96), good_sg))                           # all-zero: (0, 0) is not on the curve
+    pk = b"".join(c[0] for c in cases)
+    sg = b"".join(c[1] for c in cases)
+    ms = bytes(32 * len(cases))
+    for known in (False, True):
+        flags = 3 | (4 if known else 0)
+        ok_c, out_c, st_c = co.deserialize_sets_ex(pk, ms, sg, flags)
+        ok, out, st = m.deserializeSetsEx(cache, pk, ms, sg, pk_uncompressed=True, sig_uncompressed=True, known_on_curve=known)
+        assert (ok, st) == (ok_c, st_c), (known, list(st), list(st_c))
+        assert out == out_c
+        want = [0, 2, 5, 1, 1, 1, 3, 1, 1, 0, 4, 4, 4, 4, 1] if not known else [0, 0, 0, 1, 1, 1, 3, 1, 1, 0, 4, 4, 4, 4, 1]
+        assert list(st) == want
+    # the big-int oracle on the decode step alone
+    for pkb, sgb in cases:
+        try:
+            o.g1_deserialize(pkb); pk_ok = True
+        except ValueError:
+            pk_ok = False
+        try:
+            o.g2_deserialize(sgb); sg_ok = True
+        except ValueError:
+            sg_ok = False
+        _, _, st1 = m.deserializeSetsEx(cache, pkb, bytes(32), sgb, pk_uncompressed=True, sig_uncompressed=True, known_on_curve=True)
+        assert (st1[0] == 1) == (not pk_ok)
+        if pk_ok and st1[0] != 3:
+            assert (st1[0] == 4) == (not sg_ok)
+
+
+def test_known_on_curve_compressed_form(m, cache):
+    """fromBytesKnownOnCurve on the 48- / 96-byte forms (bls_sig_io.nim:60-79, 101-121): a curve point outside the subgroup
+    passes, the infinity public key and bad encodings still fail."""
+    import c_oracle as co
+    rng = random.Random(5)
+    base = co.make_batch(2, seed=3)
+    pk48, ms, sg96 = co.compress_sets(base)
+    p_off, q_off = _curve_point_g1(rng), _curve_point_g2(rng)
+    pk = pk48[:48] + o.g1_compress(p_off) + pk48[48:96] + bytes([0xc0]) + bytes(47)
+    sg = sg96[:96] + sg96[96:192] + o.g2_compress(q_off) + sg96[:96]
+    ms4 = ms + ms
+    ok, out, st = m.deserializeSetsEx(cache, pk, ms4, sg, known_on_curve=True)
+    assert not ok and list(st) == [0, 0, 0, 3]
+    assert (False, out, st) == co.deserialize_sets_ex(pk, ms4, sg, 4)
+    ok, out, st = m.deserializeSetsEx(cache, pk, ms4, sg)
+    assert list(st) == [0, 2, 5, 3]

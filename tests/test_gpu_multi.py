@@ -93,19 +93,21 @@ def test_device_resident_blob_exchange(m):
     streams = [torch.cuda.Stream() for _ in range(world)]
     gathered = torch.zeros(world * 640, dtype=torch.uint8, device="cuda")
     fv = m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=nt)
+    mine = [torch.zeros(640, dtype=torch.uint8, device="cuda") for _ in range(world)]
+    internal = caches[0].shard_blob_ptr()
+    for g in range(world):                                          # every rank's blob goes straight to its send buffer
+        caches[g].set_shard_blob_ptr(mine[g].data_ptr())
+        assert caches[g].shard_blob_ptr() == mine[g].data_ptr()
     torch.cuda.synchronize()
 
     def run(buf):
         for g in range(world):
             lo, hi, first, count = m.shard_plan(n, nt, world, g)
             caches[g].shard_submit_device(buf.data_ptr() + 320 * first, n, lo, hi, RND, streams[g].cuda_stream)
-        # "all_gather": copy every rank's blob into its slot, each on that rank's stream, then join on stream 0
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
+        # "all_gather": every rank's blob (written by its submit into its own send buffer) into its slot, on that rank's stream
         for g in range(world):
-            rc = hip.hipMemcpyAsync(ctypes.c_void_p(gathered.data_ptr() + 640 * g), ctypes.c_void_p(caches[g].shard_blob_ptr()), ctypes.c_size_t(640),
-                                    ctypes.c_int(3), ctypes.c_void_p(streams[g].cuda_stream))
-            assert rc == 0
+            with torch.cuda.stream(streams[g]):
+                gathered[640 * g:640 * (g + 1)].copy_(mine[g], non_blocking=True)
         for g in range(1, world):
             streams[0].wait_stream(streams[g])
         fv.finalverify_blobs_submit(gathered.data_ptr(), world, 640, streams[0].cuda_stream)
@@ -126,6 +128,8 @@ def test_device_resident_blob_exchange(m):
     assert blob0[576:580] == bytes(4)
     with pytest.raises(m.BlsGpuError):
         fv.finalverify_wait()                                      # nothing pending
+    caches[0].set_shard_blob_ptr(None)
+    assert caches[0].shard_blob_ptr() == internal
 
 
 def test_batch_verify_once(m):

@@ -226,3 +226,51 @@ def test_deserialisation(emu):
     assert emu.emu_deserialize_tuple(pk, o.g2_compress(_random_curve_point_g2(rng))) == 5
     assert emu.emu_deserialize_tuple(pk, bad) == 4
     assert emu.emu_deserialize_tuple(pk, bytes([0xc0]) + bytes(95)) == 0                                      # infinity signature allowed
+
+
+def test_mad_census_pins_the_bench_model(emu):
+    """bench.py's roofline.int_mad multiplies MAD_PER_TUPLE by the tuple rate; the table is the census of the formulas the
+    kernels run (one tuple through each stage of the one-lane-per-tuple pipeline), measured here from the real code."""
+    import bench
+    emu.emu_mad_census.restype = ctypes.c_ulonglong
+    emu.emu_mad_census.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64]
+    c = [x for x in golden("batch")["cases"] if x["name"] == "n17"][0]
+    rec = bytes.fromhex(c["sets"])
+    names = ["k_hash_map", "k_hash_clear", "k_pkmul", "k_sig_bucket", "k_lines", "k_lineprod"]
+    for i in (0, 5, 16):
+        for st, name in enumerate(names):
+            got = emu.emu_mad_census(st, rec[320 * i:320 * i + 320], 0x9e3779b97f4a7c15 ^ (i << 7))
+            assert abs(got - bench.MAD_PER_TUPLE[name]) <= 0.02 * bench.MAD_PER_TUPLE[name], (name, got)
+    assert 3.9e6 < sum(bench.MAD_PER_TUPLE.values()) < 4.1e6
+
+
+def test_uncompressed_deserialisation(emu):
+    """g1_deserialize / g2_deserialize (blst_pN_deserialize semantics) on the CPU build of the device code against the
+    big-int oracle: round trips, compressed-in-first-half, infinity, bad encodings."""
+    rng = random.Random(8)
+    for _ in range(3):
+        p = o.g1_mul(o.G1_GEN, rng.randrange(1, o.R))
+        q = o.g2_mul(o.G2_GEN, rng.randrange(1, o.R))
+        inf = ctypes.c_int()
+        out = buf(96)
+        assert emu.emu_g1_deserialize(o.g1_serialize(p), out, ctypes.byref(inf)) == 1 and inf.value == 0
+        assert out.raw == o.g1_to_blst_affine(p)
+        assert emu.emu_g1_deserialize(o.g1_compress(p) + bytes(48), out, ctypes.byref(inf)) == 1 and out.raw == o.g1_to_blst_affine(p)
+        out2 = buf(192)
+        assert emu.emu_g2_deserialize(o.g2_serialize(q), out2, ctypes.byref(inf)) == 1 and inf.value == 0
+        assert out2.raw == o.g2_to_blst_affine(q)
+        assert emu.emu_g2_deserialize(o.g2_compress(q) + bytes(96), out2, ctypes.byref(inf)) == 1 and out2.raw == o.g2_to_blst_affine(q)
+        bad = bytearray(o.g1_serialize(p)); bad[60] ^= 1
+        assert emu.emu_g1_deserialize(bytes(bad), out, ctypes.byref(inf)) == 0
+        bad = bytearray(o.g2_serialize(q)); bad[150] ^= 1
+        assert emu.emu_g2_deserialize(bytes(bad), out2, ctypes.byref(inf)) == 0
+        assert emu.emu_deserialize_tuple_ex(o.g1_serialize(p), o.g2_serialize(q), 3) == 0
+        assert emu.emu_deserialize_tuple_ex(o.g1_serialize(p), o.g2_compress(q), 1) == 0
+    inf = ctypes.c_int()
+    out, out2 = buf(96), buf(192)
+    assert emu.emu_g1_deserialize(bytes([0x40]) + bytes(95), out, ctypes.byref(inf)) == 1 and inf.value == 1
+    assert emu.emu_g1_deserialize(bytes([0x40]) + bytes(94) + b"\x01", out, ctypes.byref(inf)) == 0
+    assert emu.emu_g1_deserialize(bytes(96), out, ctypes.byref(inf)) == 0
+    assert emu.emu_g2_deserialize(bytes([0x40]) + bytes(191), out2, ctypes.byref(inf)) == 1 and inf.value == 1
+    assert emu.emu_g2_deserialize(bytes([0x60]) + bytes(191), out2, ctypes.byref(inf)) == 0
+    assert emu.emu_g1_deserialize(o.P.to_bytes(48, "big") + bytes(48), out, ctypes.byref(inf)) == 0
