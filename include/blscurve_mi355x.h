@@ -172,6 +172,15 @@ int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const 
  * signature: the function prints the error and aborts. */
 size_t mi355_p1s_mult_pippenger_scratch_sizeof(size_t npoints);
 void mi355_p1s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch);
+/* EXACTLY blst_p2s_mult_pippenger / ..._scratch_sizeof (blst+nim.h:90-92; blst_abi.nim:358-362; call site
+ * blst_min_pubkey_sig_core.nim:639-646): the same on G2 (points: blst_p2_affine, 192 B; ret: blst_p2, 288 B). */
+size_t mi355_p2s_mult_pippenger_scratch_sizeof(size_t npoints);
+void mi355_p2s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch);
+/* context forms on G2 (32-byte scalar images, host or device arrays), as the mi355_bls_p1s_* pair */
+int mi355_bls_p2s_mult_pippenger(mi355_bls_ctx* ctx, uint8_t ret_p2[288], const void* const points[], size_t npoints,
+                                 const uint8_t* const scalars[], size_t nbits);
+int mi355_bls_p2s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p2[288], const void* d_points, size_t npoints,
+                                        const void* d_scalars, size_t nbits, void* stream);
 
 /* same with both arrays resident in device memory */
 int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_points, size_t npoints,
@@ -217,8 +226,9 @@ float mi355_bls_last_deser_ms(mi355_bls_ctx* ctx);   /* duration of the deserial
 /* combine(secureRandomBytes, publicKeys, signatures) (blst_min_pubkey_sig_core.nim:570-647; called by
  * MultiSignatureSet.combine, bls_batch_verifier.nim:100-106): linear combination of n signatures on ONE message.
  * Scalars: chain seeded with rnd itself, taking the u64 words 3,2,1,0 of each SHA-256 output, zeros skipped
- * (:588-606); out_pk = sum [s_i]PK_i and out_sig = sum [s_i]S_i as affine BLST images (the reference's two
- * 64-bit Pippenger calls + finish).  n == 1: passthrough; n == 0: MI355_BLS_ERR_ARG (the reference asserts).
+ * (:588-606); out_pk = sum [s_i]PK_i and out_sig = sum [s_i]S_i as affine BLST images: two 64-bit Pippenger runs on the
+ * device (G1 and G2 bucket kernels, the reference's blst_p1s/p2s_mult_pippenger calls, :629-646) + finish.  The scalar chain
+ * is sequential SHA-256: it runs on the calling host thread.  n == 1: passthrough; n == 0: MI355_BLS_ERR_ARG (the reference asserts).
  * pks: n x 96 B, sigs: n x 192 B, host memory.  Returns 0 on success. */
 int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks, const void* sigs, size_t n, uint8_t out_pk[96],
                       uint8_t out_sig[192]);

@@ -74,6 +74,12 @@ def lib():
         L.mi355_p1s_mult_pippenger_scratch_sizeof.restype = sz
         L.mi355_p1s_mult_pippenger.argtypes = [vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, vp]
         L.mi355_p1s_mult_pippenger.restype = None
+        L.mi355_p2s_mult_pippenger_scratch_sizeof.argtypes = [sz]
+        L.mi355_p2s_mult_pippenger_scratch_sizeof.restype = sz
+        L.mi355_p2s_mult_pippenger.argtypes = [vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, vp]
+        L.mi355_p2s_mult_pippenger.restype = None
+        L.mi355_bls_p2s_mult_pippenger.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
+        L.mi355_bls_p2s_mult_pippenger_device.argtypes = [vp, ctypes.c_char_p, vp, sz, vp, sz, vp]
         L.mi355_bls_g1_aggregate.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
@@ -346,29 +352,41 @@ def p1s_mult_pippenger(cache, points, scalars, nbits=255):
     return out.raw
 
 
-def blst_p1s_mult_pippenger(points, scalars, nbits=255, per_element_pointers=False):
-    """mi355_p1s_mult_pippenger: EXACTLY blst_p1s_mult_pippenger's argument list (no context, void, scalars
-    (nbits + 7) // 8 bytes apart, NULL-terminated pointer lists).  per_element_pointers: pass one pointer per element instead
-    of [ptr, NULL] (both are blst conventions).  Returns the 144-byte blst_p1."""
+def blst_p1s_mult_pippenger(points, scalars, nbits=255, per_element_pointers=False, g2=False):
+    """mi355_p1s_mult_pippenger / mi355_p2s_mult_pippenger (g2=True): EXACTLY blst_pNs_mult_pippenger's argument list (no
+    context, void, scalars (nbits + 7) // 8 bytes apart, NULL-terminated pointer lists).  per_element_pointers: pass one
+    pointer per element instead of [ptr, NULL] (both are blst conventions).  Returns the 144-byte blst_p1 / 288-byte blst_p2."""
     sb = (nbits + 7) // 8
-    if len(points) % 96 or len(scalars) % sb or len(points) // 96 != len(scalars) // sb:
-        raise ValueError("points: n x 96 bytes, scalars: n x %d bytes" % sb)
-    n = len(points) // 96
-    out = ctypes.create_string_buffer(144)
+    ab = 192 if g2 else 96
+    fn = lib().mi355_p2s_mult_pippenger if g2 else lib().mi355_p1s_mult_pippenger
+    if len(points) % ab or len(scalars) % sb or len(points) // ab != len(scalars) // sb:
+        raise ValueError("points: n x %d bytes, scalars: n x %d bytes" % (ab, sb))
+    n = len(points) // ab
+    out = ctypes.create_string_buffer(288 if g2 else 144)
     if n == 0:
-        lib().mi355_p1s_mult_pippenger(out, None, 0, None, nbits, None)
+        fn(out, None, 0, None, nbits, None)
         return out.raw
     pb = ctypes.create_string_buffer(bytes(points), len(points))
     scb = ctypes.create_string_buffer(bytes(scalars), len(scalars))
     pa, sa = ctypes.addressof(pb), ctypes.addressof(scb)
     if per_element_pointers:
-        pl = (ctypes.c_void_p * n)(*[pa + 96 * i for i in range(n)])
+        pl = (ctypes.c_void_p * n)(*[pa + ab * i for i in range(n)])
         sl = (ctypes.c_void_p * n)(*[sa + sb * i for i in range(n)])
     else:
         pl = (ctypes.c_void_p * 2)(pa, None)
         sl = (ctypes.c_void_p * 2)(sa, None)
     scratch = ctypes.create_string_buffer(max(8, lib().mi355_p1s_mult_pippenger_scratch_sizeof(n)))
-    lib().mi355_p1s_mult_pippenger(out, pl, n, sl, nbits, scratch)
+    fn(out, pl, n, sl, nbits, scratch)
+    return out.raw
+
+
+def blst_p2s_mult_pippenger(points, scalars, nbits=255, per_element_pointers=False):
+    return blst_p1s_mult_pippenger(points, scalars, nbits, per_element_pointers, g2=True)
+
+
+def p2s_mult_pippenger_device(cache, d_points, n, d_scalars, nbits=255, stream=0):
+    out = ctypes.create_string_buffer(288)
+    _check(lib().mi355_bls_p2s_mult_pippenger_device(cache._h, out, d_points, n, d_scalars, nbits, stream))
     return out.raw
 
 

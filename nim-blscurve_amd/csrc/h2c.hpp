@@ -214,17 +214,47 @@ BLS_HD g2_jac g2_psi(const g2_jac& p) {
 // [x]P, x = -0xd201000000010000
 BLS_HD g2_jac g2_mul_x(const g2_jac& p) { return jac_neg(jac_mul_u64_jac(p, k::X_ABS)); }
 
-// h_eff clearing, RFC 9380 appendix G.3: [x^2-x-1]P + [x-1]psi(P) + psi^2(2P)
+// Where the base point of a doubling chain waits between its five additions: a plain copy here; k_hash_clear parks it in LDS
+// (three Fp2 slots), so that it holds no registers during the 63 doublings.
+struct g2_park_regs {
+    g2_jac v;
+    BLS_HD void put(const g2_jac& a) { v = a; }
+    BLS_HD g2_jac get() const { return v; }
+};
+
+// h_eff clearing, RFC 9380 appendix G.3 (Budroni-Pintore): [x^2 - x - 1]P + [x - 1]psi(P) + psi^2(2P)
+//   = psi^2(2P) - psi(P) - [x]P - P  +  [x]([x]P + psi(P))
+// written as ONE copy of the 63-doubling chain executed twice (pass 0: t1 = [x]P; pass 1: [x](t1 + psi(P))), with the chain's
+// accumulator a plain loop-carried value: inlined into the kernel it lives in registers for the whole chain (as the return
+// value of an out-of-line [x]-multiplication it lived in scratch memory and was stored back 84 words per doubling).
+template <class Park>
+BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
+    g2_jac base = p, u = p, res = p;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < 2; pass++) {
+        park.put(base);
+        g2_jac acc = base;                                   // bit 63 of |x|
+#pragma clang loop unroll(disable)
+        for (int i = 62; i >= 0; i--) {
+            acc = jac_dbl(acc);
+            if ((k::X_ABS >> i) & 1) acc = jac_add_body(acc, park.get());
+        }
+        acc = jac_neg(acc);                                  // x < 0
+        if (pass == 0) {
+            g2_jac t2 = g2_psi(p);
+            u = jac_add(g2_psi(g2_psi(jac_dbl(p))), jac_neg(t2));        // psi^2(2P) - psi(P)
+            u = jac_add(u, jac_neg(acc));                                // - [x]P
+            u = jac_add(u, jac_neg(p));                                  // - P
+            base = jac_add(acc, t2);                                     // [x]P + psi(P)
+        } else {
+            res = jac_add(u, acc);
+        }
+    }
+    return res;
+}
 BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
-    g2_jac t1 = g2_mul_x(p);
-    g2_jac t2 = g2_psi(p);
-    g2_jac t3 = g2_psi(g2_psi(jac_dbl(p)));
-    t3 = jac_add(t3, jac_neg(t2));
-    t2 = jac_add(t1, t2);
-    t2 = g2_mul_x(t2);
-    t3 = jac_add(t3, t2);
-    t3 = jac_add(t3, jac_neg(t1));
-    return jac_add(t3, jac_neg(p));
+    g2_park_regs park;
+    return clear_cofactor_g2_with(p, park);
 }
 
 BLS_HDN g2_jac hash_to_g2(const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {

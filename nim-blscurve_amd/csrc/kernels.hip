@@ -271,11 +271,23 @@ __global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict_
     fp2 u = fp2_select((t & 1) != 0, u1, u0);
     soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
 }
+// base point of the doubling chains parked in three LDS slots (21 KB of the 40 KB a wave may use)
+struct g2_park_lds {
+    bls_lds_u32x4* base;
+    __device__ __forceinline__ void put(const g2_jac& a) const {
+        fp2_lds_put(base, a.x);
+        fp2_lds_put(base + BLS_LDS_SLOT, a.y);
+        fp2_lds_put(base + 2 * BLS_LDS_SLOT, a.z);
+    }
+    __device__ __forceinline__ g2_jac get() const { return g2_jac{fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT), fp2_lds_get(base + 2 * BLS_LDS_SLOT)}; }
+};
 __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    __shared__ bls_u32x4 park_slots[3 * BLS_LDS_SLOT];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
-    soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
+    g2_park_lds park{(bls_lds_u32x4*)park_slots};
+    soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park));
 }
 
 // arbitrary-length message (fastAggregateVerify / coreVerify shape): ONE message, so latency is all that matters.
@@ -841,16 +853,8 @@ __global__ void k_fav_setup(const uint32_t* __restrict__ agg, const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------
-// G1 Pippenger multi-scalar multiplication: sum_i [k_i mod 2^nbits] P_i   (replaces
-// blst_p1s_mult_pippenger, blst_abi.nim:336-340; shape of benchmarks/bls12381_msm_g1.nim:22-59).
-//   k_msm_hist     per point: window digits -> bucket histogram (global atomics)
-//   k_msm_scan     per window: exclusive scan of the histogram -> bucket offsets
-//   k_msm_scatter  per point: point index into its bucket's slice, per window (counting sort)
-//   k_msm_bucket   one lane per (window, bucket): sum of its points with mixed additions
-//   k_msm_segred   one lane per segment of L buckets: running sums -> sum_b b*B_b of the segment
-//   k_msm_winsum   per window: sum of its segment values (wave-shuffle tree), times 2^(c*w)
-//   k_msm_final    sum over windows
-// Buckets live in HBM as SoA Jacobian points (151 MB at 16 windows x 2^16 buckets).
+// Counting-sort helpers shared by the signature-side bucket fold (unsigned digits of the 64-bit blinding scalars) and,
+// for the scan, by the Pippenger kernels further down.
 // ------------------------------------------------------------------------------------------
 // Window w covers bits [off_w, off_w + len_w): the nbits are split into nwin windows whose widths differ by
 // at most one bit (wbase + 1 for the first wrem windows, wbase after) so that no window is short and
@@ -906,32 +910,93 @@ __global__ void __launch_bounds__(WAVE) k_msm_scatter(const uint8_t* __restrict_
         sorted[(size_t)w * n + pos] = i;
     }
 }
-// points are converted once from the blst image to the device representation (2 multiplications per
-// point instead of 2 per bucket addition): internal AoS, 2 x FPW words per point
-__global__ void __launch_bounds__(WAVE) k_msm_convert(const uint8_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ pts_int) {
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
-    if (i >= n) return;
-    g1_aff q = ld_g1a_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * 96));
-    st_fp_int(pts_int + (size_t)i * 2 * FPW, q.x);
-    st_fp_int(pts_int + (size_t)i * 2 * FPW + FPW, q.y);
+// ------------------------------------------------------------------------------------------
+// Pippenger for G1 AND G2 (blst_p1s_mult_pippenger / blst_p2s_mult_pippenger, blst_abi.nim:336-362), templated on the
+// coordinate field, with SIGNED window digits: k' = k + H, H = sum_w 2^(off_w + len_w - 1), makes every window digit of k' minus
+// its half a digit in [-2^(len-1), 2^(len-1) - 1]; a negative digit adds the negated point (free: -y), so a window needs
+// 2^(len-1) buckets instead of 2^len and the running-sum reduction halves.  The windows cover nbits + 1 bits (the extra top bit
+// of k is zero): the TOP window is left unbiased and absorbs the carry of the bias, its digit stays within 0 .. 2^(len-1).
+// Bucket b of a window holds the points with |digit| = b + 1.
+//   k_pip_hist / k_msm_scan / k_pip_scatter   counting sort of (point, sign) by window and |digit|; lane per (point, window)
+//   k_msm_order_*                             buckets ordered by load so that a wave's lanes do equal work
+//   k_pip_bucket    lane per bucket: sum of its signed points (mixed additions)
+//   k_pip_segred    lane per segment of 16 buckets: running sums -> sum (b + 1) B_b of the segment
+//   k_pip_winpart / k_pip_winsum    per window: sum of the segment values, times 2^(off_w) (lane-parallel doubling chain)
+//   k_pip_final     sum over the windows -> blst_p1 / blst_p2 image
+// ------------------------------------------------------------------------------------------
+struct pip_win {
+    uint32_t nwin, wbase, wrem, nbits;      // nwin windows over nbits + 1 bits (widths differ by at most one bit)
+    uint32_t cbk;                           // bucket index bits: 2^cbk buckets per window, cbk = widest window - 1
+    uint32_t H[9];                          // the bias: 2^(len - 1) at every window but the top one
+};
+__device__ __forceinline__ uint32_t pip_off(const pip_win& W, uint32_t w) {
+    return w < W.wrem ? w * (W.wbase + 1) : W.wrem * (W.wbase + 1) + (w - W.wrem) * W.wbase;
 }
-// lane per (window, bucket); `order` (optional) lists the buckets so that a wave's lanes have similar counts
-__global__ void __launch_bounds__(WAVE) k_msm_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
-                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t c,
-                                                     uint32_t total, uint4* __restrict__ buckets) {
-    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
-    if (t >= total) return;
-    uint32_t g = order ? order[t] : t;
-    uint32_t w = g >> c, cnt = hist[g], off = offs[g];
-    const uint32_t* srt = sorted + (size_t)w * n + off;
-    g1_jac acc = jac_inf<fp>();
-    for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t* pw = pts + (size_t)srt[j] * (2 * FPW);
-        g1_aff q{ld_fp_int(pw), ld_fp_int(pw + FPW)};
-        acc = jac_add_aff(acc, q);
+// k' = (k mod 2^nbits) + H as 9 words; scalars little-endian, sbytes each
+__device__ __forceinline__ void pip_biased(uint32_t (&kp)[9], const uint8_t* __restrict__ sc, size_t i, const pip_win& W, uint32_t sbytes) {
+    const uint8_t* p = sc + i * sbytes;
+    uint32_t k[8];
+    if ((sbytes & 3) == 0 && (((uintptr_t)sc) & 3) == 0) {
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = (uint32_t)(4 * j) < sbytes ? pw[j] : 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t v = 0;
+            for (int q = 0; q < 4; q++)
+                if ((uint32_t)(4 * j + q) < sbytes) v |= (uint32_t)p[4 * j + q] << (8 * q);
+            k[j] = v;
+        }
     }
-    soa_st_g1(buckets, total, g, acc);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t lo = (uint32_t)(32 * j), v = k[j];
+        if (W.nbits <= lo) v = 0;
+        else if (W.nbits < lo + 32) v &= (1u << (W.nbits - lo)) - 1u;
+        uint64_t t = (uint64_t)v + W.H[j] + carry;
+        kp[j] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+    kp[8] = W.H[8] + carry;
 }
+__device__ __forceinline__ uint32_t pip_bits(const uint32_t (&kp)[9], uint32_t bit0, uint32_t len) {     // len <= 31
+    uint32_t wi = bit0 >> 5, sh = bit0 & 31;
+    uint64_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+        if ((uint32_t)j == wi) v = kp[j] | ((uint64_t)(j < 8 ? kp[j + 1 > 8 ? 8 : j + 1] : 0u) << 32);
+    return (uint32_t)(v >> sh) & ((1u << len) - 1u);
+}
+// signed digit of window w; the top window is unbiased (0 .. 2^(len-1), carry of the bias included)
+__device__ __forceinline__ int32_t pip_digit(const uint32_t (&kp)[9], uint32_t w, const pip_win& W) {
+    uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase;
+    int32_t raw = (int32_t)pip_bits(kp, pip_off(W, w), len);
+    return w + 1 == W.nwin ? raw : raw - (int32_t)(1u << (len - 1));
+}
+// lane per (point, window)
+__global__ void __launch_bounds__(WAVE) k_pip_hist(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t* __restrict__ hist) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
+    if (i >= n) return;
+    uint32_t kp[9];
+    pip_biased(kp, sc, i, W, sbytes);
+    int32_t d = pip_digit(kp, w, W);
+    if (d) atomicAdd(&hist[((size_t)w << W.cbk) + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
+}
+__global__ void __launch_bounds__(WAVE) k_pip_scatter(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t* __restrict__ cursor,
+                                                      uint32_t* __restrict__ sorted) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
+    if (i >= n) return;
+    uint32_t kp[9];
+    pip_biased(kp, sc, i, W, sbytes);
+    int32_t d = pip_digit(kp, w, W);
+    if (d) {
+        uint32_t pos = atomicAdd(&cursor[((size_t)w << W.cbk) + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
+        sorted[(size_t)w * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
+    }
+}
+
 // buckets ordered by point count (descending) with a counting sort on min(count, 255)
 // Each wave bins MSM_ORD_PER buckets per lane into an LDS histogram first, so the 256 global bins see
 // one atomic per (wave, bin) instead of one per bucket.
@@ -981,42 +1046,98 @@ __global__ void __launch_bounds__(WAVE) k_msm_order_scatter(const uint32_t* __re
     for (uint32_t j = 0; j < MSM_ORD_PER; j++)
         if (bin[j] != 0xffffffffu) order[h[bin[j]] + rank[j]] = base + j * WAVE + threadIdx.x;
 }
-// lane per (window, segment of L buckets): W = sum_{b in seg} b * B_b
-__global__ void __launch_bounds__(WAVE) k_msm_segred(const uint4* __restrict__ buckets, uint32_t total, uint32_t c, uint32_t L, uint32_t nseg_total,
+
+// field-generic memory helpers
+__device__ __forceinline__ g1_aff ld_aff_blst(const uint32_t* w, const g1_aff*) { return ld_g1a_blst(w); }
+__device__ __forceinline__ g2_aff ld_aff_blst(const uint32_t* w, const g2_aff*) { return ld_g2a_blst(w); }
+__device__ __forceinline__ void st_aff_int(uint32_t* o, const g1_aff& q) { st_fp_int(o, q.x); st_fp_int(o + FPW, q.y); }
+__device__ __forceinline__ void st_aff_int(uint32_t* o, const g2_aff& q) {
+    st_fp_int(o, q.x.c0); st_fp_int(o + FPW, q.x.c1); st_fp_int(o + 2 * FPW, q.y.c0); st_fp_int(o + 3 * FPW, q.y.c1);
+}
+__device__ __forceinline__ g1_aff ld_aff_int(const uint32_t* w, const g1_aff*) { return g1_aff{ld_fp_int(w), ld_fp_int(w + FPW)}; }
+__device__ __forceinline__ g2_aff ld_aff_int(const uint32_t* w, const g2_aff*) {
+    return g2_aff{fp2{ld_fp_int(w), ld_fp_int(w + FPW)}, fp2{ld_fp_int(w + 2 * FPW), ld_fp_int(w + 3 * FPW)}};
+}
+__device__ __forceinline__ g1_jac soa_ld_jac(const uint4* b, size_t stride, size_t i, const g1_jac*) { return soa_ld_g1(b, stride, i); }
+__device__ __forceinline__ g2_jac soa_ld_jac(const uint4* b, size_t stride, size_t i, const g2_jac*) { return soa_ld_g2(b, stride, i); }
+__device__ __forceinline__ void soa_st_jac(uint4* b, size_t stride, size_t i, const g1_jac& a) { soa_st_g1(b, stride, i, a); }
+__device__ __forceinline__ void soa_st_jac(uint4* b, size_t stride, size_t i, const g2_jac& a) { soa_st_g2(b, stride, i, a); }
+__device__ __forceinline__ g1_jac ld_jac_int(const uint32_t* w, const g1_jac*) { return ld_g1_int(w); }
+__device__ __forceinline__ g2_jac ld_jac_int(const uint32_t* w, const g2_jac*) { return ld_g2_int(w); }
+__device__ __forceinline__ void st_jac_int(uint32_t* w, const g1_jac& a) { st_g1_int(w, a); }
+__device__ __forceinline__ void st_jac_int(uint32_t* w, const g2_jac& a) { st_g2_int(w, a); }
+__device__ __forceinline__ void st_jac_blst(uint32_t* w, const g1_jac& a) { st_g1_blst(w, a); }
+__device__ __forceinline__ void st_jac_blst(uint32_t* w, const g2_jac& a) { st_g2_blst(w, a); }
+template <class F> struct fld;                      // words of one coordinate in the internal AoS form
+template <> struct fld<fp> { static constexpr int W = FPW; static constexpr int AFFB = 96; };
+template <> struct fld<fp2> { static constexpr int W = 2 * FPW; static constexpr int AFFB = 192; };
+// additions inside loops: inlined for G1 (operands stay in registers), the shared out-of-line body for G2 (code size)
+__device__ __forceinline__ g1_jac padd(const g1_jac& a, const g1_jac& b) { return jac_add_body(a, b); }
+__device__ __forceinline__ g2_jac padd(const g2_jac& a, const g2_jac& b) { return jac_add(a, b); }
+
+// points converted once from the blst image to the device representation (2 multiplications per coordinate instead of per
+// bucket addition): internal AoS
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_convert(const uint8_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ pts_int) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    aff<F> q = ld_aff_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * fld<F>::AFFB), (const aff<F>*)nullptr);
+    st_aff_int(pts_int + (size_t)i * 2 * fld<F>::W, q);
+}
+// lane per (window, bucket); `order` lists the buckets so that a wave's lanes have similar counts
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t cbk,
+                                                     uint32_t total, uint4* __restrict__ buckets) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= total) return;
+    uint32_t g = order ? order[t] : t;
+    uint32_t w = g >> cbk, cnt = hist[g], off = offs[g];
+    const uint32_t* srt = sorted + (size_t)w * n + off;
+    jac<F> acc = jac_inf<F>();
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t e = srt[j];
+        aff<F> q = ld_aff_int(pts + (size_t)(e & 0x7fffffffu) * (2 * fld<F>::W), (const aff<F>*)nullptr);
+        if (e >> 31) q.y = f_neg(q.y);
+        acc = jac_add_aff(acc, q);
+    }
+    soa_st_jac(buckets, total, g, acc);
+}
+// lane per (window, segment of L buckets): sum_{j < L} (b0 + j + 1) * B_{b0 + j}
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_segred(const uint4* __restrict__ buckets, uint32_t total, uint32_t cbk, uint32_t L, uint32_t nseg_total,
                                                      uint4* __restrict__ segout) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
     if (t >= nseg_total) return;
-    uint32_t segs_per_win = (1u << c) / L;
+    uint32_t segs_per_win = (1u << cbk) / L;
     uint32_t w = t / segs_per_win, b0 = (t % segs_per_win) * L;
-    g1_jac S = jac_inf<fp>(), T = jac_inf<fp>();
+    jac<F> S = jac_inf<F>(), T = jac_inf<F>();
     for (uint32_t j = L; j-- > 0;) {
-        g1_jac B = soa_ld_g1(buckets, total, ((size_t)w << c) | (b0 + j));
-        S = jac_add_body(S, B);       // inlined additions: the running sums stay in registers
-        T = jac_add_body(T, S);       // T = sum (j+1) * B_{b0+j}
+        jac<F> B = soa_ld_jac(buckets, total, ((size_t)w << cbk) | (b0 + j), (const jac<F>*)nullptr);
+        S = padd(S, B);               // running sums
+        T = padd(T, S);               // T = sum (j + 1) * B_{b0 + j}
     }
-    // W = T + (b0 - 1) * S, b0 < 2^c
-    g1_jac acc = jac_inf<fp>();
+    jac<F> acc = jac_inf<F>();        // [b0] S, b0 < 2^cbk
 #pragma clang loop unroll(disable)
-    for (int i = (int)c - 1; i >= 0; i--) {
+    for (int i = (int)cbk - 1; i >= 0; i--) {
         acc = jac_dbl(acc);
-        if ((b0 >> i) & 1) acc = jac_add_body(acc, S);
+        if ((b0 >> i) & 1) acc = padd(acc, S);
     }
-    acc = jac_add(acc, jac_neg(S));
-    acc = jac_add(acc, T);
-    soa_st_g1(segout, nseg_total, t, acc);
+    acc = padd(acc, T);
+    soa_st_jac(segout, nseg_total, t, acc);
 }
-// grid (nwin, nsplit): partial sums of a window's segment values
-__global__ void __launch_bounds__(WAVE) k_msm_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t* __restrict__ part) {
+// grid (windows, nsplit): partial sums of a window's segment values
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t* __restrict__ part) {
     uint32_t w = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
-    g1_jac acc = jac_inf<fp>();
-    for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit) acc = jac_add_body(acc, soa_ld_g1(segout, nseg_total, (size_t)w * segs_per_win + j));
+    jac<F> acc = jac_inf<F>();
+    for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit)
+        acc = padd(acc, soa_ld_jac(segout, nseg_total, (size_t)w * segs_per_win + j, (const jac<F>*)nullptr));
     for (int d = 32; d >= 1; d >>= 1) {
-        g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add_body(acc, o);
+        jac<F> o = shfl_down_struct(acc, d);
+        acc = padd(acc, o);
     }
-    if (threadIdx.x == 0) {
-        st_g1_int(part + ((size_t)w * nsplit + sp) * G1W, acc);
-    }
+    if (threadIdx.x == 0) st_jac_int(part + ((size_t)w * nsplit + sp) * (3 * fld<F>::W), acc);
 }
 // Lane-parallel G1 doubling for the serial doubling chains: every lane holds the same point; the three independent
 // products of each of the first two rounds of dbl-2009-l run in lanes 0, 1, 2 of ONE multiplier call and are then
@@ -1042,22 +1163,38 @@ __device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) {
     r.z = fp_carry(fp_dbl_nc(YZ));
     return r;
 }
+__device__ __forceinline__ g1_jac dbl_coop(const g1_jac& p) { return g1_dbl_coop(p); }
+__device__ __forceinline__ g2_jac dbl_coop(const g2_jac& p) { return g2_dbl_coop(p, threadIdx.x & ~7u, threadIdx.x & 7u); }
+__device__ __forceinline__ g1_jac bcast0(const g1_jac& a) { return g1_jac{fp_bcast(a.x, 0), fp_bcast(a.y, 0), fp_bcast(a.z, 0)}; }
+__device__ __forceinline__ g2_jac bcast0(const g2_jac& a) {
+    return g2_jac{fp2{fp_bcast(a.x.c0, 0), fp_bcast(a.x.c1, 0)}, fp2{fp_bcast(a.y.c0, 0), fp_bcast(a.y.c1, 0)}, fp2{fp_bcast(a.z.c0, 0), fp_bcast(a.z.c1, 0)}};
+}
 // one wave per window: R_w = sum of its nsplit partial sums, then 2^(off_w) * R_w
-__global__ void __launch_bounds__(WAVE) k_msm_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, msm_win W, uint32_t* __restrict__ winout) {
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, pip_win W, uint32_t* __restrict__ winout) {
     uint32_t w = blockIdx.x;
-    g1_jac acc = jac_inf<fp>();
-    for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) {
-        acc = jac_add_body(acc, ld_g1_int(part + ((size_t)w * nsplit + j) * G1W));
-    }
+    jac<F> acc = jac_inf<F>();
+    for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) acc = padd(acc, ld_jac_int(part + ((size_t)w * nsplit + j) * (3 * fld<F>::W), (const jac<F>*)nullptr));
     for (int d = 32; d >= 1; d >>= 1) {
-        g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add_body(acc, o);
+        jac<F> o = shfl_down_struct(acc, d);
+        acc = padd(acc, o);
     }
-    acc = g1_jac{fp_bcast(acc.x, 0), fp_bcast(acc.y, 0), fp_bcast(acc.z, 0)};
-    uint32_t sh = msm_win_off(W, w);
+    acc = bcast0(acc);
+    uint32_t sh = pip_off(W, w);
 #pragma clang loop unroll(disable)
-    for (uint32_t i = 0; i < sh; i++) acc = g1_dbl_coop(acc);
-    if (threadIdx.x == 0) st_g1_int(winout + (size_t)w * G1W, acc);
+    for (uint32_t i = 0; i < sh; i++) acc = dbl_coop(acc);
+    if (threadIdx.x == 0) st_jac_int(winout + (size_t)w * (3 * fld<F>::W), acc);
+}
+// one wave: sum of the window values -> blst image (Jacobian)
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_pip_final(const uint32_t* __restrict__ winout, uint32_t nparts, uint32_t* __restrict__ out) {
+    jac<F> acc = jac_inf<F>();
+    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = padd(acc, ld_jac_int(winout + (size_t)j * (3 * fld<F>::W), (const jac<F>*)nullptr));
+    for (int d = 32; d >= 1; d >>= 1) {
+        jac<F> o = shfl_down_struct(acc, d);
+        acc = padd(acc, o);
+    }
+    if (threadIdx.x == 0) st_jac_blst(out, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1167,17 +1304,6 @@ __global__ void __launch_bounds__(WAVE) k_deser(const uint8_t* __restrict__ pks,
 //   s_i: chain seeded with rnd ITSELF, u64 words 3,2,1,0 of every digest, zeros skipped (:588-606)
 //   pk' = sum [s_i]PK_i, sig' = sum [s_i]S_i  (the reference's two 64-bit Pippenger calls, :629-646)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_g1mul_sum(const uint8_t* __restrict__ pts, size_t stride_b, size_t offset_b, uint32_t n, const uint64_t* __restrict__ r,
-                                                    uint32_t* __restrict__ part) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    g1_jac acc = jac_inf<fp>();
-    if (i < n) acc = jac_mul_u64(ld_g1a_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * stride_b + offset_b)), r[i]);
-    for (int d = 32; d >= 1; d >>= 1) {
-        g1_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
-    }
-    if (threadIdx.x == 0) st_g1_int(part + (size_t)blockIdx.x * G1W, acc);
-}
 // `finish` (to affine, core :172-177 / blst_p{1,2}_to_affine): Jacobian blst images -> affine blst images
 __global__ void k_finish_affine(const uint32_t* __restrict__ p1, const uint32_t* __restrict__ p2, uint32_t* __restrict__ out_pk, uint32_t* __restrict__ out_sig) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1298,8 +1424,8 @@ __global__ void k_export_g1(const uint4* __restrict__ P, size_t stride, uint32_t
 // Context
 // ------------------------------------------------------------------------------------------
 struct msm_ws {
-    size_t cap_n = 0;
-    uint32_t cap_total = 0, cap_seg = 0;
+    size_t cap_n = 0;                 // capacity of d_pts in bytes
+    uint32_t cap_total = 0;
     uint8_t* d_pts = nullptr;
     uint8_t* d_sc = nullptr;
     uint32_t* pts_int = nullptr;
@@ -2093,28 +2219,48 @@ extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks
 }
 
 // ------------------------------------------------------------------------------------------
-// blst_p1s_mult_pippenger replacement
+// blst_p1s_mult_pippenger / blst_p2s_mult_pippenger replacement (host side)
 // ------------------------------------------------------------------------------------------
-static uint32_t msm_window_bits(size_t n) {
-    uint32_t lg = 0;
-    while ((1ull << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 4;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return (uint32_t)c;
-}
 constexpr uint32_t MSM_SEG = 16;
+
+// Window plan for npoints x nbits: about log2(n) - 3 bits per window (signed digits: 2^(c-1) buckets), widths balanced.
+static pip_win pip_plan(size_t npoints, size_t nbits) {
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= npoints) lg++;
+    int c = (int)lg - 3;
+    if (c < 5) c = 5;                                   // at least one 16-bucket segment per window
+    if (c > 17) c = 17;
+    pip_win W{};
+    W.nbits = (uint32_t)nbits;
+    uint32_t ext = (uint32_t)nbits + 1;                  // one extra (zero) top bit: the top window absorbs the carry of the bias
+    W.nwin = (ext + c - 1) / c;
+    W.wbase = ext / W.nwin;
+    W.wrem = ext % W.nwin;
+    uint32_t widest = W.wbase + (W.wrem ? 1 : 0);
+    W.cbk = widest - 1;
+    if (W.cbk < 4) W.cbk = 4;
+    for (int j = 0; j < 9; j++) W.H[j] = 0;
+    for (uint32_t w = 0; w + 1 < W.nwin; w++) {
+        uint32_t off = w < W.wrem ? w * (W.wbase + 1) : W.wrem * (W.wbase + 1) + (w - W.wrem) * W.wbase;
+        uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase;
+        uint32_t bit = off + len - 1;                    // + 2^(len - 1) at window w
+        W.H[bit >> 5] |= 1u << (bit & 31);
+    }
+    return W;
+}
 
 extern "C" size_t mi355_bls_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
     (void)npoints;
     return 0;          // blst_p1s_mult_pippenger_scratch_sizeof (blst_abi.nim:336): the workspace lives on the device
 }
 
-static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
+// workspace for npoints points of `affb`-byte affine images (96: G1, 192: G2) under window plan W
+static int msm_reserve(mi355_bls_ctx* c, size_t n, const pip_win& W, size_t affb) {
     msm_ws* m = c->msm;
-    uint32_t total = nwin << cb, nseg = total / MSM_SEG;
-    if (n <= m->cap_n && total <= m->cap_total) return 0;
-    size_t cn = n > m->cap_n ? n : m->cap_n;
+    uint32_t total = W.nwin << W.cbk;
+    size_t pts_bytes = n * affb;
+    if (pts_bytes <= m->cap_n && total <= m->cap_total) return 0;
+    size_t cb = pts_bytes > m->cap_n ? pts_bytes : m->cap_n;
     uint32_t ct = total > m->cap_total ? total : m->cap_total;
     msm_free(m);
 #define MALLOC(p, bytes)                                                                   \
@@ -2126,7 +2272,8 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
             return MI355_BLS_ERR_HIP;                                                      \
         }                                                                                  \
     } while (0)
-    MALLOC(m->d_pts, cn * 96);
+    size_t cn = cb / 96;                                 // point capacity counted in G1 points (a G2 point takes two)
+    MALLOC(m->d_pts, cb);
     MALLOC(m->d_sc, cn * 32);
     MALLOC(m->pts_int, cn * 2 * FPW * 4);
     MALLOC(m->hist, (size_t)ct * 4);
@@ -2134,74 +2281,89 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, uint32_t nwin, uint32_t cb) {
     MALLOC(m->cursor, (size_t)ct * 4);
     MALLOC(m->order, (size_t)ct * 4);
     MALLOC(m->chist, 256 * 4);
-    MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 64 windows (nbits 256 at c = 4)
-    MALLOC(m->buckets, (size_t)ct * 3 * 64);
-    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 3 * 64);
-    MALLOC(m->winout, 64 * G1W * 4);
-    MALLOC(m->out, 144);
+    MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 52 + 1 windows (nbits 256 at 5-bit windows)
+    MALLOC(m->buckets, (size_t)ct * 6 * 64);
+    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 6 * 64);
+    MALLOC(m->winout, 64 * G2W * 4);
+    MALLOC(m->out, 288);
 #undef MALLOC
-    m->cap_n = cn;
+    m->cap_n = cb;
     m->cap_total = ct;
-    m->cap_seg = nseg;
     return 0;
 }
 
-// sbytes: distance between scalars (32 for blst_scalar images; blst's own convention is (nbits + 7) / 8)
-static int msm_g1_run(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits,
-                      void* stream) {
-    if (!c || !ret_p1 || nbits == 0 || nbits > 256 || npoints > (1u << 28) || sbytes * 8 < nbits) return MI355_BLS_ERR_ARG;
+// sum_i [k_i mod 2^nbits] P_i on the device.  sbytes: distance between scalars (32 for blst_scalar images; blst's own
+// convention is (nbits + 7) / 8).  ret: blst_p1 (144 B) or blst_p2 (288 B), host memory.
+template <class F>
+static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits, void* stream) {
+    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192, JACB = AFFB / 2 * 3;
+    if (!c || !ret || nbits == 0 || nbits > 256 || npoints > (1u << 28) || (size_t)sbytes * 8 < nbits || sbytes > 32) return MI355_BLS_ERR_ARG;
     if (npoints == 0) {
-        memset(ret_p1, 0, 144);
+        memset(ret, 0, JACB);
         return 0;
     }
     if (!d_points || !d_scalars) return MI355_BLS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    uint32_t n = (uint32_t)npoints, c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
-    msm_win W{nwin, (uint32_t)nbits / nwin, (uint32_t)nbits % nwin};
-    uint32_t cb = W.wbase + (W.wrem ? 1 : 0);           // bucket index bits per window
-    if (cb < 4) cb = 4;                                  // at least one 16-bucket segment per window
-    int rc = msm_reserve(c, npoints, nwin, cb);
+    pip_win W = pip_plan(npoints, nbits);
+    int rc = msm_reserve(c, npoints, W, AFFB);
     if (rc) return rc;
     msm_ws* m = c->msm;
-    uint32_t total = nwin << cb, segs_per_win = (1u << cb) / MSM_SEG, nseg = nwin * segs_per_win;
+    uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, segs_per_win = (1u << W.cbk) / MSM_SEG, nseg = nw * segs_per_win;
     const uint8_t* pts = (const uint8_t*)d_points;
     const uint8_t* sc = (const uint8_t*)d_scalars;
     uint32_t nbp = (n + WAVE - 1) / WAVE, nbt = (total + WAVE - 1) / WAVE;
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
     HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
-    k_msm_convert<<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
-    k_msm_hist<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, sbytes, n, W, cb, m->hist);
-    k_msm_scan<<<nwin, WAVE, 0, st>>>(m->hist, cb, m->offs, m->cursor);
-    k_msm_scatter<<<dim3(nbp, nwin), WAVE, 0, st>>>(sc, sbytes, n, W, cb, m->cursor, m->sorted);
+    k_pip_convert<F><<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
+    k_pip_hist<<<dim3(nbp, nw), WAVE, 0, st>>>(sc, sbytes, n, W, m->hist);
+    k_msm_scan<<<nw, WAVE, 0, st>>>(m->hist, W.cbk, m->offs, m->cursor);
+    k_pip_scatter<<<dim3(nbp, nw), WAVE, 0, st>>>(sc, sbytes, n, W, m->cursor, m->sorted);
     uint32_t nbo = (total + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
     k_msm_order_hist<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist);
     k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
     k_msm_order_scatter<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_msm_bucket<<<nbt, WAVE, 0, st>>>(m->pts_int, m->sorted, m->offs, m->hist, m->order, n, cb, total, m->buckets);
+    k_pip_bucket<F><<<nbt, WAVE, 0, st>>>(m->pts_int, m->sorted, m->offs, m->hist, m->order, n, W.cbk, total, m->buckets);
     HIPCHK(hipEventRecord(c->ev[2], st));
-    k_msm_segred<<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, cb, MSM_SEG, nseg, m->segout);
+    k_pip_segred<F><<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, W.cbk, MSM_SEG, nseg, m->segout);
     HIPCHK(hipEventRecord(c->ev[3], st));
     uint32_t nsplit = segs_per_win >= 1024 ? 16 : (segs_per_win >= 128 ? 4 : 1);
-    k_msm_winpart<<<dim3(nwin, nsplit), WAVE, 0, st>>>(m->segout, nseg, segs_per_win, reinterpret_cast<uint32_t*>(m->buckets));
-    k_msm_winsum<<<nwin, WAVE, 0, st>>>(reinterpret_cast<const uint32_t*>(m->buckets), nsplit, W, m->winout);
-    k_g1_sum2<<<1, WAVE, 0, st>>>(m->winout, nwin, m->out);
+    k_pip_winpart<F><<<dim3(nw, nsplit), WAVE, 0, st>>>(m->segout, nseg, segs_per_win, reinterpret_cast<uint32_t*>(m->buckets));
+    k_pip_winsum<F><<<nw, WAVE, 0, st>>>(reinterpret_cast<const uint32_t*>(m->buckets), nsplit, W, m->winout);
+    k_pip_final<F><<<1, WAVE, 0, st>>>(m->winout, nw, m->out);
     HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ret_p1, m->out, 144, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ret, m->out, JACB, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return collect_timings(c, 4);       // [0] sort, [1] bucket accumulation, [2] segment reduction, [3] window sums + doublings
 }
 extern "C" int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_points, size_t npoints, const void* d_scalars,
                                                    size_t nbits, void* stream) {
-    return msm_g1_run(c, ret_p1, d_points, npoints, d_scalars, 32, nbits, stream);
+    return msm_run<fp>(c, ret_p1, d_points, npoints, d_scalars, 32, nbits, stream);
+}
+extern "C" int mi355_bls_p2s_mult_pippenger_device(mi355_bls_ctx* c, uint8_t ret_p2[288], const void* d_points, size_t npoints, const void* d_scalars,
+                                                   size_t nbits, void* stream) {
+    return msm_run<fp2>(c, ret_p2, d_points, npoints, d_scalars, 32, nbits, stream);
+}
+
+// host arrays (contiguous) -> staging -> msm_run
+template <class F>
+static int msm_host(mi355_bls_ctx* c, uint8_t* ret, const uint8_t* pts, size_t npoints, const uint8_t* scalars, uint32_t sbytes, size_t nbits) {
+    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192;
+    if (!c || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = msm_reserve(c, npoints, pip_plan(npoints, nbits), AFFB);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->msm->d_pts, pts, npoints * AFFB, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars, npoints * sbytes, hipMemcpyHostToDevice, nullptr));
+    return msm_run<F>(c, ret, c->msm->d_pts, npoints, c->msm->d_sc, sbytes, nbits, nullptr);
 }
 
 // Same shape as blst_p1s_mult_pippenger incl. the NULL-terminated pointer-to-array convention
-// (blst+nim.h:70-72; benchmarks/bls12381_msm_g1.nim:52-59): points[0] / scalars[0] are contiguous
-// arrays of npoints blst_p1_affine / 32-byte little-endian scalars in HOST memory.
+// (blst+nim.h:70-72; benchmarks/bls12381_msm_g1.nim:52-59), but with a context, an int result and 32-byte scalar images
+// (blst_scalar arrays) whatever nbits is: points[0] / scalars[0] are contiguous arrays in HOST memory.
 extern "C" int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* const points[], size_t npoints,
                                             const uint8_t* const scalars[], size_t nbits) {
     if (!c || !ret_p1) return MI355_BLS_ERR_ARG;
@@ -2210,15 +2372,17 @@ extern "C" int mi355_bls_p1s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p1[144
         return 0;
     }
     if (!points || !points[0] || !scalars || !scalars[0] || nbits == 0 || nbits > 256) return MI355_BLS_ERR_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    uint32_t c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
-    uint32_t cb = (uint32_t)nbits / nwin + (((uint32_t)nbits % nwin) ? 1 : 0);
-    if (cb < 4) cb = 4;
-    int rc = msm_reserve(c, npoints, nwin, cb);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->msm->d_pts, points[0], npoints * 96, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars[0], npoints * 32, hipMemcpyHostToDevice, nullptr));
-    return mi355_bls_p1s_mult_pippenger_device(c, ret_p1, c->msm->d_pts, npoints, c->msm->d_sc, nbits, nullptr);
+    return msm_host<fp>(c, ret_p1, (const uint8_t*)points[0], npoints, scalars[0], 32, nbits);
+}
+extern "C" int mi355_bls_p2s_mult_pippenger(mi355_bls_ctx* c, uint8_t ret_p2[288], const void* const points[], size_t npoints,
+                                            const uint8_t* const scalars[], size_t nbits) {
+    if (!c || !ret_p2) return MI355_BLS_ERR_ARG;
+    if (npoints == 0) {
+        memset(ret_p2, 0, 288);
+        return 0;
+    }
+    if (!points || !points[0] || !scalars || !scalars[0] || nbits == 0 || nbits > 256) return MI355_BLS_ERR_ARG;
+    return msm_host<fp2>(c, ret_p2, (const uint8_t*)points[0], npoints, scalars[0], 32, nbits);
 }
 
 // blst's list convention (blst_p1s_mult_pippenger and friends): list[0] points at element 0; for every following element the
@@ -2244,40 +2408,45 @@ static const uint8_t* gather_list(const void* const list[], size_t n, size_t ele
     std::abort();
 }
 
-// EXACTLY blst_p1s_mult_pippenger (blst+nim.h:70-72, blst_abi.nim:336-340): no context (the process-wide default one), void,
-// scalars (nbits + 7) / 8 bytes apart, scratch ignored (the workspace lives on the device).
-extern "C" size_t mi355_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
-    (void)npoints;
-    return 8;                       // never 0: callers malloc() it (benchmarks/bls12381_msm_g1.nim:50) and index scratch[0] (core :633)
-}
-extern "C" void mi355_p1s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch) {
-    (void)scratch;
+// EXACTLY blst_p1s_mult_pippenger / blst_p2s_mult_pippenger (blst+nim.h:70-72,90-92; blst_abi.nim:336-340,358-362): no context
+// (the process-wide default one), void, scalars (nbits + 7) / 8 bytes apart, scratch ignored (the workspace lives on the device).
+template <class F>
+static void blst_shaped_pippenger(const char* fn, void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits) {
+    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192, JACB = AFFB / 2 * 3;
     if (!ret) return;
     if (npoints == 0) {
-        std::memset(ret, 0, 144);
+        std::memset(ret, 0, JACB);
         return;
     }
     if (!points || !points[0] || !scalars || !scalars[0] || nbits == 0 || nbits > 256) {
         g_err = "bad arguments";
-        die_no_error_channel("mi355_p1s_mult_pippenger");
+        die_no_error_channel(fn);
     }
     std::lock_guard<std::mutex> lk(g_default_mu);
     mi355_bls_ctx* c;
     uint32_t sbytes = (uint32_t)((nbits + 7) / 8);
     std::vector<uint8_t> tp, ts;
-    const uint8_t* P = gather_list(points, npoints, 96, tp);
+    const uint8_t* P = gather_list(points, npoints, AFFB, tp);
     const uint8_t* S = gather_list(reinterpret_cast<const void* const*>(scalars), npoints, sbytes, ts);
     int rc = default_ctx_locked(1024, &c);
-    if (!rc) {
-        uint32_t c0 = msm_window_bits(npoints), nwin = ((uint32_t)nbits + c0 - 1) / c0;
-        uint32_t cb = (uint32_t)nbits / nwin + (((uint32_t)nbits % nwin) ? 1 : 0);
-        if (cb < 4) cb = 4;
-        rc = msm_reserve(c, npoints, nwin, cb);
-    }
-    if (!rc && hipMemcpyAsync(c->msm->d_pts, P, npoints * 96, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = MI355_BLS_ERR_HIP, g_err = "H2D copy of the points";
-    if (!rc && hipMemcpyAsync(c->msm->d_sc, S, npoints * sbytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = MI355_BLS_ERR_HIP, g_err = "H2D copy of the scalars";
-    if (!rc) rc = msm_g1_run(c, (uint8_t*)ret, c->msm->d_pts, npoints, c->msm->d_sc, sbytes, nbits, nullptr);
-    if (rc) die_no_error_channel("mi355_p1s_mult_pippenger");
+    if (!rc) rc = msm_host<F>(c, (uint8_t*)ret, P, npoints, S, sbytes, nbits);
+    if (rc) die_no_error_channel(fn);
+}
+extern "C" size_t mi355_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
+    (void)npoints;
+    return 8;                       // never 0: callers malloc() it (benchmarks/bls12381_msm_g1.nim:50) and index scratch[0] (core :633)
+}
+extern "C" size_t mi355_p2s_mult_pippenger_scratch_sizeof(size_t npoints) {
+    (void)npoints;
+    return 8;
+}
+extern "C" void mi355_p1s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch) {
+    (void)scratch;
+    blst_shaped_pippenger<fp>("mi355_p1s_mult_pippenger", ret, points, npoints, scalars, nbits);
+}
+extern "C" void mi355_p2s_mult_pippenger(void* ret, const void* const points[], size_t npoints, const uint8_t* const scalars[], size_t nbits, void* scratch) {
+    (void)scratch;
+    blst_shaped_pippenger<fp2>("mi355_p2s_mult_pippenger", ret, points, npoints, scalars, nbits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2440,27 +2609,32 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
     uint8_t* d_sg = c->d_sets + n * 96;
     HIPCHK(hipMemcpyAsync(d_pk, pks, n * 96, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_sg, sigs, n * 192, hipMemcpyHostToDevice, st));
-    uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE;
-    HIPCHK(hipEventRecord(c->ev[0], st));
     c->h_r.resize(n);
     host_combine_chain(rnd, n, c->h_r.data());
     HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), n * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(c->ev[1], st));
-    k_g1mul_sum<<<nb, WAVE, 0, st>>>(d_pk, 96, 0, n32, c->d_r, c->d_export);
-    k_g1_sum2<<<1, WAVE, 0, st>>>(c->d_export, nb, c->d_agg1);
-    HIPCHK(hipEventRecord(c->ev[2], st));
-    k_sigmul<<<nb, WAVE, 0, st>>>(d_sg, 192, 0, n32, c->d_r, c->d_spart);
-    k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
-    HIPCHK(hipEventRecord(c->ev[3], st));
+    // the reference's two 64-bit Pippenger calls (core :629-646): 8-byte scalars, nbits = 64
+    uint8_t p1[144], p2[288];
+    int rc = msm_run<fp>(c, p1, d_pk, n, c->d_r, 8, 64, st);
+    if (rc) return rc;
+    float t_g1 = c->timings[7];
+    rc = msm_run<fp2>(c, p2, d_sg, n, c->d_r, 8, 64, st);
+    if (rc) return rc;
+    float t_g2 = c->timings[7];
+    // `finish` (to affine, core :172-177)
+    HIPCHK(hipMemcpyAsync(c->d_agg1, p1, 144, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_agg, p2, 288, hipMemcpyHostToDevice, st));
     uint32_t* d_out = reinterpret_cast<uint32_t*>(c->d_msg);
     k_finish_affine<<<1, 1, 0, st>>>(c->d_agg1, c->d_agg, d_out, d_out + 24);
-    HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_pk, d_out, 96, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_sig, d_out + 24, 192, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    c->timings[1] = t_g1;             // G1 Pippenger
+    c->timings[2] = t_g2;             // G2 Pippenger
+    c->timings[7] = t_g1 + t_g2;
     c->last_n = n;                  // fetch_stage(0) returns the combine scalars
-    return collect_timings(c, 4);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------

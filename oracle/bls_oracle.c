@@ -728,6 +728,50 @@ void oracle_msm_g1_pippenger(const uint8_t* pts, const uint8_t* scalars, size_t 
     free(win);
     g1a r = g1_to_aff(&acc); st_g1a(out96, &r);
 }
+/* naive G2 MSM (blst_p2s_mult_pippenger semantics): sum [k_i mod 2^nbits] Q_i, scalars `sbytes` apart -> affine */
+void oracle_msm_g2(const uint8_t* pts, const uint8_t* scalars, size_t n, int sbytes, int nbits, uint8_t out192[192]) {
+    g2j acc = g2_inf();
+#pragma omp parallel
+    {
+        g2j loc = g2_inf();
+#pragma omp for schedule(static)
+        for (long i = 0; i < (long)n; i++) { g2a a = ld_g2a(pts + 192 * i); g2j j = g2_from_aff(&a), m = g2_mul(&j, scalars + (size_t)sbytes * i, nbits); loc = g2_add(&loc, &m); }
+#pragma omp critical
+        acc = g2_add(&acc, &loc);
+    }
+    g2a r = g2_to_aff(&acc); st_g2a(out192, &r);
+}
+/* combine (blst_min_pubkey_sig_core.nim:570-647): scalars = u64 words 3,2,1,0 of a SHA-256 chain seeded with rnd itself, zeros
+ * skipped; out_pk = sum [s_i]PK_i, out_sig = sum [s_i]S_i, affine.  scalars_out (optional): n u64. */
+void oracle_combine(const uint8_t rnd[32], const uint8_t* pks, const uint8_t* sigs, size_t n, uint8_t out_pk[96], uint8_t out_sig[192], uint64_t* scalars_out) {
+    uint64_t* sc = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint8_t seed[32]; memcpy(seed, rnd, 32);
+    int avail = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (;;) {
+            if (avail == 0) { uint8_t nx[32]; oracle_sha256(seed, 32, nx); memcpy(seed, nx, 32); avail = 4; }
+            avail--;
+            uint64_t w = 0; for (int j = 7; j >= 0; j--) w = (w << 8) | seed[8 * avail + j];
+            if (w) { sc[i] = w; break; }
+        }
+    }
+    g1j a1 = g1_inf(); g2j a2 = g2_inf();
+#pragma omp parallel
+    {
+        g1j l1 = g1_inf(); g2j l2 = g2_inf();
+#pragma omp for schedule(static)
+        for (long i = 0; i < (long)n; i++) {
+            g1a p = ld_g1a(pks + 96 * i); g1j pj = g1_from_aff(&p), m1 = g1_mul_u64(&pj, sc[i]); l1 = g1_add(&l1, &m1);
+            g2a q = ld_g2a(sigs + 192 * i); g2j qj = g2_from_aff(&q), m2 = g2_mul_u64(&qj, sc[i]); l2 = g2_add(&l2, &m2);
+        }
+#pragma omp critical
+        { a1 = g1_add(&a1, &l1); a2 = g2_add(&a2, &l2); }
+    }
+    g1a r1 = g1_to_aff(&a1); st_g1a(out_pk, &r1);
+    g2a r2 = g2_to_aff(&a2); st_g2a(out_sig, &r2);
+    if (scalars_out) memcpy(scalars_out, sc, n * sizeof(uint64_t));
+    free(sc);
+}
 /* coreVerify (blst_min_pubkey_sig_core.nim:269-297; `verify`, bls_sig_min_pubkey.nim:100-107): e(pk, H(msg)) == e(G1, sig) */
 int oracle_core_verify(const uint8_t pk96[96], const uint8_t* msg, size_t mlen, const uint8_t sig192[192]) {
     return oracle_fast_aggregate_verify(pk96, 1, msg, mlen, sig192);

@@ -30,6 +30,8 @@ def lib():
         L.oracle_sha256.argtypes = [cp, sz, cp]
         L.oracle_msm_g1_pippenger.argtypes = [cp, cp, sz, i32, cp]
         L.oracle_core_verify.argtypes = [cp, cp, sz, cp]
+        L.oracle_msm_g2.argtypes = [cp, cp, sz, i32, i32, cp]
+        L.oracle_combine.argtypes = [cp, cp, cp, sz, cp, cp, vp]
         L.oracle_set_num_threads.argtypes = [i32]
         L.oracle_set_num_threads.restype = None
         _lib = L
@@ -151,3 +153,18 @@ def deserialize_sets_ex(pks, msgs, sigs, flags):
     out, st = ctypes.create_string_buffer(320 * n), ctypes.create_string_buffer(n)
     ok = lib().oracle_deserialize_sets_ex(pks, msgs, sigs, n, flags, out, st)
     return bool(ok), out.raw, st.raw
+
+
+def msm_g2(pts, scalars, nbits=255, sbytes=32):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_msm_g2(pts, scalars, len(pts) // 192, sbytes, nbits, o)
+    return o.raw
+
+
+def combine(rnd, pks, sigs):
+    """-> (out_pk96, out_sig192, [scalars])"""
+    n = len(pks) // 96
+    pk, sg = ctypes.create_string_buffer(96), ctypes.create_string_buffer(192)
+    sc = (ctypes.c_uint64 * n)()
+    lib().oracle_combine(rnd, pks, sigs, n, pk, sg, sc)
+    return pk.raw, sg.raw, list(sc)

@@ -108,3 +108,22 @@ def test_core_verify():
     pk, msg = co.sk_to_pk(sk), b"Mr F was here"
     sig = co.sign(sk, msg)
     assert co.core_verify(pk, msg, sig) and not co.core_verify(pk, msg + b"!", sig)
+
+
+def test_combine_and_g2_msm_restatements():
+    """oracle_combine against the fixture made by the KAT-pinned python oracle (scalars in word order 3,2,1,0, combined key and
+    signature), and oracle_msm_g2 against python big-int G2 arithmetic."""
+    import random
+    g = golden("batch")["combine"]
+    pk, sg, sc = co.combine(bytes.fromhex(g["rnd"]), bytes.fromhex(g["pks"]), bytes.fromhex(g["sigs"]))
+    assert [str(x) for x in sc] == g["scalars"] and pk.hex() == g["out_pk"] and sg.hex() == g["out_sig"]
+    rng = random.Random(12)
+    sigs = bytes.fromhex(g["sigs"])[:192 * 5]
+    Q = [o.g2_from_blst_affine(sigs[192 * i:192 * i + 192]) for i in range(5)]
+    for nbits, sb in ((64, 8), (255, 32), (13, 2)):
+        K = [rng.getrandbits(8 * sb) for _ in range(5)]
+        want = None
+        for q, k in zip(Q, K):
+            want = o.g2_add(want, o.g2_mul(q, k % (1 << nbits)))
+        got = co.msm_g2(sigs, b"".join(k.to_bytes(sb, "little") for k in K), nbits, sb)
+        assert got == o.g2_to_blst_affine(want)

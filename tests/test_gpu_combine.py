@@ -46,3 +46,65 @@ def test_combine_100_same_message(m):
     assert two[0] == o.g1_to_blst_affine(want_pk)
     with pytest.raises(AssertionError):
         m.MultiSignatureSet.init([], msg, [])
+
+
+@pytest.mark.parametrize("n", [2, 33, 4096])
+def test_combine_is_two_pippenger_runs(m, n):
+    """combine = blst_p1s_mult_pippenger + blst_p2s_mult_pippenger with 64-bit scalars (core :629-646): scalars, combined key
+    and combined signature byte-exact against the C restatement at sizes where the bucket kernels really bucket; the
+    combined set verifies, a deranged one does not."""
+    import c_oracle as co
+    msg = o.sha256(b"same message")
+    sks = [1000 + 7 * i for i in range(n)]
+    base_pk = [co.sk_to_pk(s) for s in sks[:64]]
+    h = co.hash_to_g2(msg, o.DST_SIG)
+    base_sg = [co.g2_mul(h, s) for s in sks[:64]]
+    pks = [base_pk[i % 64] for i in range(n)]
+    sgs = [base_sg[i % 64] for i in range(n)]
+    rnd = o.sha256(b"combine rnd")
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=4)
+    out = m.MultiSignatureSet.init(pks, msg, sgs).combine(cache, rnd)
+    want_pk, want_sg, want_sc = co.combine(rnd, b"".join(pks), b"".join(sgs))
+    assert list(struct.unpack("<%dQ" % n, cache.fetch(0, 8 * n))) == want_sc
+    assert out[0] == want_pk and out[2] == want_sg
+    assert m.batchVerify(cache, [out], rnd) is True
+    bad = m.MultiSignatureSet.init(pks, msg, sgs[1:] + sgs[:1]).combine(cache, rnd)
+    assert m.batchVerify(cache, [bad], rnd) is False
+    print("combine", n, cache.timings())
+
+
+def test_g2_pippenger_entry_points(m):
+    """mi355_p2s_mult_pippenger (exact blst shape, both list conventions, nbits 64 / 255 / odd) and the context / device forms
+    against the C restatement's naive G2 MSM."""
+    import random
+    import c_oracle as co
+    import torch
+    from util import g2_jac_to_affine
+    rng = random.Random(2)
+    h = co.hash_to_g2(b"g2 msm", o.DST_SIG)
+    base = [co.g2_mul(h, rng.randrange(1, o.R)) for _ in range(40)]
+    for n in (1, 2, 40, 1000):
+        pts = b"".join(base[i % 40] for i in range(n))
+        for nbits in (255, 64, 21):
+            sb = (nbits + 7) // 8
+            sc = bytes(rng.getrandbits(8) for _ in range(sb * n))
+            want = co.msm_g2(pts, sc, nbits, sb)
+            for per_elem in ((False, True) if n <= 40 else (False,)):
+                got = m.blst_p2s_mult_pippenger(pts, sc, nbits, per_element_pointers=per_elem)
+                assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == want, (n, nbits, per_elem)
+    assert m.blst_p2s_mult_pippenger(b"", b"", 255) == bytes(288)
+    # infinity in the list, cancellation
+    q = o.g2_from_blst_affine(base[0])
+    pts = base[0] + bytes(192) + o.g2_to_blst_affine(o.g2_neg(q))
+    sc = (5).to_bytes(32, "little") * 3
+    assert g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, sc, 255)) is None
+    # device form, 32-byte scalars
+    n = 3000
+    pts = b"".join(base[i % 40] for i in range(n))
+    sc = bytes(rng.getrandbits(8) for _ in range(32 * n))
+    cache = m.BatchedBLSVerifierCache.init(max_sets=64)
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    got = m.p2s_mult_pippenger_device(cache, dp.data_ptr(), n, ds.data_ptr(), 255)
+    assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == co.msm_g2(pts, sc, 255, 32)
+    m.lib().mi355_bls_default_ctx_release()
