@@ -39,7 +39,7 @@ KERNEL_BYTES = {"k_hash_map": 32 + 2 * 288, "k_hash_clear": 2 * 288 + 288, "k_pk
                 "k_lineprod": 68 * 288}
 # 32x32+64-bit multiply-adds (v_mad_i64_i32 / v_mad_u64_u32) per tuple and kernel of the one-lane-per-tuple pipeline:
 # a census of the real formulas (tests/host_emu: emu_mad_census; tests/test_host_emu.py pins this table to it)
-MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1126608, "k_pkmul": 263081, "k_sig_bucket": 101920, "k_lines": 759997,
+MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 263081, "k_sig_bucket": 101920, "k_lines": 759997,
                  "k_lineprod": 1039584}
 MAD_ISSUE_CYCLES = 4.0          # one wave64 VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md, issue cost table)
 CLOCK_HZ = 2.4e9                # peak engine clock; under this load the chip sustains less (DVFS), see DESIGN.md section 4
@@ -104,7 +104,10 @@ def main():
     # bls_batch_verifier.nim:389-391) keep several batches in flight so that one batch's serial tail
     # (step products, Horner, final exponentiation: a handful of waves) overlaps another batch's wide kernels.
     caches = [m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local) for _ in range(inflight)]
-    cache = caches[0]
+    if inflight > 1:
+        for c in caches:
+            c.set_cooperative(False)            # throughput mode: several batches in flight (include/blscurve_mi355x.h)
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)      # the one blocking caller: latency mode
     fv_caches = [m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=nthreads, device=local) for _ in range(inflight)] if sharded_path else []
     lo, hi, first, count = m.shard_plan(n_total, nthreads, world, rank)
     assert count == n
@@ -311,6 +314,7 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "kernel_ms_timed_region": {k: round(v, 3) for k, v in timed_kernel_ms.items()},
             "kernel_ms_alone": {k: round(v, 3) for k, v in alone.items()},
+            "tail_ms_alone": {k: round(v, 3) for k, v in one["tail_ms_alone"].items()},
             "stage_ms_note": "stage_ms / kernel_ms_timed_region: HIP-event durations inside the timed region (with %d batches in flight they include "
                              "time shared with other batches' kernels); kernel_ms_alone: one un-overlapped caller after the timed region" % inflight,
             "input_gen_s": round(gen_s, 1),

@@ -50,9 +50,13 @@ const char* mi355_bls_last_error(void);
  * is seeded SHA256(rnd || LE64(c)) exactly as processSingleChunk does (:333-336).  Default 4096. */
 int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* ctx, uint32_t num_threads);
 
-/* Batches of up to 8 192 sets do not fill the chip with one lane per set; by default (on = 1) their cofactor clearing and
- * Miller-line kernels then use 8 lanes per set, which shortens one call (4 096 sets: 15 -> 11.6 ms) at about twice the
- * lane-work.  A caller that keeps many small batches in flight gets more throughput with on = 0. */
+/* Latency mode (on = 1, the default) or throughput mode (on = 0) of a context.
+ * Latency mode shortens ONE call at the price of some extra lane-work: batches of up to 8 192 sets (which do not fill the chip
+ * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 11.6 ms);
+ * whole-chip batches run the signature side's extra Miller pairs with 8 lanes per pair and fold the line products inside the
+ * wide kernel, so that no nearly empty round of waves follows a full one.
+ * Throughput mode does the least total work: for a caller that keeps several batches in flight (one context each), where
+ * the nearly empty rounds of one batch overlap the wide kernels of another.  Verdicts and GT values are the same. */
 int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* ctx, int on);
 
 /* batchVerifyParallel / batchVerify raw-pointer overloads (bls_batch_verifier.nim:296-302,420-426):

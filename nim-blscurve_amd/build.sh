@@ -8,14 +8,14 @@
 # step of the spliced pipeline fails, the plain one-step hipcc build is used instead (same code, unaligned).
 set -e
 cd "$(dirname "$0")"
-OUT=libblscurve_mi355x.so
+OUT=${BLS_OUT:-libblscurve_mi355x.so}
 if [ "$1" != "-f" ] && [ -f $OUT ] && [ -z "$(find csrc ../include tools/align_isa.py build.sh -newer $OUT -type f)" ]; then
   exit 0
 fi
 LLVM=/opt/rocm/lib/llvm/bin
 # --gpu-max-threads-per-block=64: every kernel is one wave per workgroup; this also gives the out-of-line device
 # functions the full 512-register (VGPR+AGPR) budget instead of the 128-VGPR default, so they stop spilling to scratch
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64 $BLS_EXTRA_FLAGS"      # BLS_EXTRA_FLAGS: -D switches of A/B experiments (tools/abn.sh)
 B=build
 mkdir -p $B
 aligned_build() {

@@ -173,7 +173,7 @@ BLS_HDN jac<F> jac_mul_u64(const aff<F>& p, uint64_t kk) {
 // 64 iterations - some lane always has the bit set; here every lane adds once per window: 64 doublings +
 // 17 additions + a table of 1..8 times P (4 doublings, 3 mixed additions) instead of 64 + 64.
 template <class F>
-BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
+BLS_MID jac<F> jac_mul_u64_w4_body(const aff<F>& p, uint64_t kk) {
     // T[i] = (i + 1) P.  One copy of the doubling and of the mixed addition in a loop: unrolled, this function
     // was 84 KB of code against a 64 KB instruction cache.
     jac<F> T[8];
@@ -209,6 +209,9 @@ BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) {
     }
     return acc;
 }
+// out-of-line form (its own register budget); k_pkmul inlines the body so that the kernel's launch bounds govern it
+template <class F>
+BLS_HDN jac<F> jac_mul_u64_w4(const aff<F>& p, uint64_t kk) { return jac_mul_u64_w4_body(p, kk); }
 
 // [k]P for Jacobian base
 template <class F>

@@ -30,6 +30,7 @@
 #include "deser.hpp"
 #include "h2c.hpp"
 #include "pairing.hpp"
+#include "c12.hpp"
 
 using namespace bls;
 
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict_
     soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
 }
 // base point of the doubling chains parked in three LDS slots (21 KB of the 40 KB a wave may use)
+#if defined(__HIP_DEVICE_COMPILE__)
 struct g2_park_lds {
     bls_lds_u32x4* base;
     __device__ __forceinline__ void put(const g2_jac& a) const {
@@ -281,12 +283,17 @@ struct g2_park_lds {
     }
     __device__ __forceinline__ g2_jac get() const { return g2_jac{fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT), fp2_lds_get(base + 2 * BLS_LDS_SLOT)}; }
 };
+#endif
 __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
-    __shared__ bls_u32x4 park_slots[3 * BLS_LDS_SLOT];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 park_slots[3 * BLS_LDS_SLOT];
     g2_park_lds park{(bls_lds_u32x4*)park_slots};
+#else
+    g2_park_regs park;               // host pass of the translation unit: kernels are parsed, never run
+#endif
     soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park));
 }
 
@@ -355,14 +362,16 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restric
     if (live && role == 0) soa_st_g2(H, stride, i, h);
 }
 
-__global__ void __launch_bounds__(WAVE) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
-                                                size_t stride, uint32_t* __restrict__ flags) {
+// G1 arithmetic has a small live set (a Jacobian point is 42 registers): 256 registers, two waves per SIMD, which fill each
+// other's issue gaps (non-multiply VALU instructions issue about twice as fast with a second wave on the SIMD)
+__global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
+                                                   size_t stride, uint32_t* __restrict__ flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
     g1_aff pk = ld_g1a_blst(w);
     if (aff_is_inf(pk)) atomicOr(flags, 1u);        // BLST_PK_IS_INFINITY -> update() false
-    g1_jac q = jac_mul_u64_w4(pk, r[i]);
+    g1_jac q = jac_mul_u64_w4_body(pk, r[i]);
     soa_st_g1(P, stride, i, q);
 }
 
@@ -577,91 +586,38 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
 // i.e. ~1.3 Fp2-mul latencies instead of 18 on a single lane.
 // ------------------------------------------------------------------------------------------
 constexpr int C12_NREG = 8;
+constexpr int TAIL_THREADS = 128;     // two waves: the 108 products of an Fp12 multiplication in ONE round
 struct c12_lds {
     fp2 r[C12_NREG][6];
-    fp prod[108];        // Karatsuba triples (t0, t1, s) of the 36 (or 21) coefficient pairs
+    c12_work w;
     fp2 frob[6];
     fp frob2[6];
+    uint32_t steps[N_LINES * 6 * 2 * FP_N];     // the 68 step products, flat basis (46 KB): loaded once, no global load per Horner step
 };
-__device__ __forceinline__ int c12_flat_of_tower(int t) { return t < 3 ? 2 * t : 2 * (t - 3) + 1; }
 
-// One Fp product of the Karatsuba triple of the coefficient pair (x, y): kind 0: x.c0*y.c0, 1: x.c1*y.c1,
-// 2: (x.c0 + x.c1)(y.c0 + y.c1).
-BLS_HD fp c12_triple(const fp2& x, const fp2& y, int kind) {
-    fp u = kind == 0 ? x.c0 : (kind == 1 ? x.c1 : fp_add_nc(x.c0, x.c1));
-    fp v = kind == 0 ? y.c0 : (kind == 1 ? y.c1 : fp_add_nc(y.c0, y.c1));
-    return fp_mul(u, v);
-}
-// acc += coef * x limb-wise (no carry), coef in {-4..4}
-BLS_HD void fp_axpy_nc(fp& acc, const fp& x, int coef) {
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) acc.l[i] += (uint32_t)(coef * (int32_t)x.l[i]);
-}
-// Adds coefficient `comp` of mult * (Fp2 product given by its Karatsuba triple t = (t0, t1, s)), times
-// xi = 1 + u for wrapped terms, to acc, then one carry step:
-//   plain:   re = t0 - t1        im = s - t0 - t1
-//   wrapped: re - im = 2 t0 - s  re + im = s - 2 t1
-// At most 6 limb units of 2^28 are added to a semi-normalised accumulator: |limbs| < 2^31 before the carry.
-BLS_HD void c12_accumulate(fp& acc, const fp* t, int comp, bool wrap, int mult) {
-    int c0 = comp ? (wrap ? 0 : -1) : (wrap ? 2 : 1);
-    int c1 = comp ? (wrap ? -2 : -1) : (wrap ? 0 : -1);
-    int cs = comp ? 1 : (wrap ? -1 : 0);
-    fp_axpy_nc(acc, t[0], c0 * mult);
-    fp_axpy_nc(acc, t[1], c1 * mult);
-    fp_axpy_nc(acc, t[2], cs * mult);
-    fp_carry_step(acc.l);
-}
-
-// d = a * b.  108 Fp products in two rounds over 54 lanes, then 12 lanes x one 6-term column sum.
+// d = a * b (flat basis); d may be a or b
 __device__ __noinline__ void c12_mul(c12_lds& S, int d, int a, int b) {
     int lane = threadIdx.x;
-    if (lane < 54) {
-#pragma unroll 1
-        for (int rnd = 0; rnd < 2; rnd++) {
-            int q = lane + 54 * rnd, pr = q / 3, kind = q % 3;
-            S.prod[q] = c12_triple(S.r[a][pr / 6], S.r[b][pr % 6], kind);
-        }
-    }
+    if (lane < 108) S.w.prod[lane] = c12_phase1(S.r[a], S.r[b], lane, false);
+    __syncthreads();
+    for (int t = lane; t < 12 * FP_N; t += TAIL_THREADS) c12_phase2a(S.w, t, false);
     __syncthreads();
     if (lane < 12) {
-        int kk = lane >> 1, comp = lane & 1;
-        fp acc = fp_zero();
-        for (int i = 0; i < 6; i++) {
-            int j = kk - i;
-            bool wrap = j < 0;
-            if (wrap) j += 6;
-            c12_accumulate(acc, &S.prod[3 * (i * 6 + j)], comp, wrap, 1);
-        }
-        acc = fp_reduce(acc);          // keeps the stored coefficients at |v| < p: bounds never accumulate
-        if (comp) S.r[d][kk].c1 = acc; else S.r[d][kk].c0 = acc;
+        fp v = c12_phase2b(S.w, lane);
+        if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
     }
     __syncthreads();
 }
-// d = a^2.  Only the 21 pairs i <= j are formed: 63 Fp products, ONE round over 63 lanes.
+// d = a^2: only the 21 pairs i <= j are formed, 63 Fp products
 __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
     int lane = threadIdx.x;
-    if (lane < 63) {
-        int pr = lane / 3, kind = lane % 3;
-        // pair index -> (i, j), i <= j, enumerated row by row: i = 0: j = 0..5 (6), i = 1: 5, ...
-        int i = 0, base = 0;
-        while (pr >= base + (6 - i)) { base += 6 - i; i++; }
-        int j = i + (pr - base);
-        S.prod[lane] = c12_triple(S.r[a][i], S.r[a][j], kind);
-    }
+    if (lane < 63) S.w.prod[lane] = c12_phase1(S.r[a], S.r[a], lane, true);
+    __syncthreads();
+    for (int t = lane; t < 12 * FP_N; t += TAIL_THREADS) c12_phase2a(S.w, t, true);
     __syncthreads();
     if (lane < 12) {
-        int kk = lane >> 1, comp = lane & 1;
-        fp acc = fp_zero();
-        for (int i = 0; i < 6; i++) {
-            int j = kk - i;
-            bool wrap = j < 0;
-            if (wrap) j += 6;
-            if (i > j) continue;                               // (j, i) already counted, doubled
-            int pr = i * 6 - (i * (i - 1)) / 2 + (j - i);      // index of the pair (i, j) in the i <= j enumeration
-            c12_accumulate(acc, &S.prod[3 * pr], comp, wrap, i == j ? 1 : 2);
-        }
-        acc = fp_reduce(acc);
-        if (comp) S.r[d][kk].c1 = acc; else S.r[d][kk].c0 = acc;
+        fp v = c12_phase2b(S.w, lane);
+        if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
     }
     __syncthreads();
 }
@@ -690,9 +646,17 @@ __device__ __forceinline__ void c12_load(c12_lds& S, int d, const uint32_t* g) {
     if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_blst(g + 24 * lane), ld_fp_blst(g + 24 * lane + 12)};
     __syncthreads();
 }
-__device__ __forceinline__ void c12_load_int(c12_lds& S, int d, const uint32_t* g) {   // internal Fp12 (F12W words)
+// step product s (internal Fp12 layout: tower order, FPW words per Fp) from the LDS copy
+__device__ __forceinline__ void c12_load_step(c12_lds& S, int d, int s) {
     int lane = threadIdx.x;
-    if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_int(g + 2 * FPW * lane), ld_fp_int(g + 2 * FPW * lane + FPW)};
+    if (lane < 12) {
+        const uint32_t* w = S.steps + ((size_t)s * 12 + lane) * FP_N;
+        fp v;
+#pragma unroll
+        for (int i = 0; i < FP_N; i++) v.l[i] = w[i];
+        fp2& dst = S.r[d][c12_flat_of_tower(lane >> 1)];
+        if (lane & 1) dst.c1 = v; else dst.c0 = v;
+    }
     __syncthreads();
 }
 __device__ __forceinline__ void c12_store(const c12_lds& S, int a, uint32_t* g) {
@@ -718,23 +682,27 @@ __device__ __noinline__ void c12_cyc_exp_x(c12_lds& S, int d, int a, int tmp) {
     }
     c12_conj(S, d, tmp);
 }
-// single-lane inverse (one Fp inversion inside): the only non-parallel step of the tail
-__device__ __noinline__ void c12_inv(c12_lds& S, int d, int a) {
+// d = 1 / a = conj_6(a) / (a conj_6(a)): the norm to Fp6 and the last product run on the lane-parallel engine; the Fp6
+// inversion (one Fp inversion inside: the only long single-lane step of the tail) on lane 0.  t1, t2: scratch registers.
+__device__ __noinline__ void c12_inv(c12_lds& S, int d, int a, int t1, int t2) {
+    c12_conj(S, t1, a);                    // (c0, -c1)
+    c12_mul(S, t2, a, t1);                 // c0^2 - v c1^2: an Fp6 element, odd powers of w are zero
     if (threadIdx.x == 0) {
-        fp12 f{fp6{S.r[a][0], S.r[a][2], S.r[a][4]}, fp6{S.r[a][1], S.r[a][3], S.r[a][5]}};
-        fp12 g = fp12_inv(f);
-        S.r[d][0] = g.c0.a0; S.r[d][2] = g.c0.a1; S.r[d][4] = g.c0.a2;
-        S.r[d][1] = g.c1.a0; S.r[d][3] = g.c1.a1; S.r[d][5] = g.c1.a2;
+        fp6 n{S.r[t2][0], S.r[t2][2], S.r[t2][4]};
+        fp6 ni = fp6_inv(n);
+        S.r[t2][0] = ni.a0; S.r[t2][2] = ni.a1; S.r[t2][4] = ni.a2;
+        S.r[t2][1] = fp2_zero(); S.r[t2][3] = fp2_zero(); S.r[t2][5] = fp2_zero();
     }
     __syncthreads();
+    c12_mul(S, d, t1, t2);
 }
 
-// One wave.  mode bit 0: Horner-combine the 68 step products L -> state slot 0 (Miller value);
+// One block of two waves.  mode bit 0: Horner-combine the 68 step products L -> state slot 0 (Miller value);
 // bit 1: multiply the kk states and run the final exponentiation -> gt_out, verdict.
 // sstride: distance in words between the kk states (144 = packed blst_fp12 images); blob != 0: every state is followed by
 // its shard's ok word (1 = no update failed), and the verdict also requires all of them.
-__global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
-                                               uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
+__global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
+                                                       uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
     __shared__ c12_lds S;
     int lane = threadIdx.x;
     if (lane == 0) {
@@ -742,6 +710,10 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         S.frob[3] = fp2_from_const(k::FROB_G3); S.frob[4] = fp2_from_const(k::FROB_G4); S.frob[5] = fp2_from_const(k::FROB_G5);
         S.frob2[0] = fp_one(); S.frob2[1] = fp_from_const(k::FROB2_G1); S.frob2[2] = fp_from_const(k::FROB2_G2);
         S.frob2[3] = fp_from_const(k::FROB2_G3); S.frob2[4] = fp_from_const(k::FROB2_G4); S.frob2[5] = fp_from_const(k::FROB2_G5);
+    }
+    if (mode & 1) {
+        // all 68 step products into LDS, dropping the two pad words of every Fp
+        for (int e = lane; e < N_LINES * 12 * FP_N; e += TAIL_THREADS) S.steps[e] = L[(size_t)(e / FP_N) * FPW + (e % FP_N)];
     }
     __syncthreads();
     enum { F = 0, T = 1, A = 2, B = 3, C = 4, X1 = 5, X2 = 6, X3 = 7 };
@@ -751,10 +723,10 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
         int s = 0;
         for (int bit = 62; bit >= 0; bit--) {
             c12_sqr(S, F, F);
-            c12_load_int(S, X1, L + (size_t)(s++) * F12W);
+            c12_load_step(S, X1, s++);
             c12_mul(S, F, F, X1);
             if ((k::X_ABS >> bit) & 1) {
-                c12_load_int(S, X1, L + (size_t)(s++) * F12W);
+                c12_load_step(S, X1, s++);
                 c12_mul(S, F, F, X1);
             }
         }
@@ -768,7 +740,7 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
             c12_mul(S, F, F, X1);
         }
         // easy part: t = conj(f)/f ; t = frob2(t) * t
-        c12_inv(S, X1, F);
+        c12_inv(S, X1, F, X2, X3);
         c12_conj(S, X2, F);
         c12_mul(S, T, X2, X1);
         c12_frob2(S, X1, T);
@@ -809,7 +781,7 @@ __global__ void __launch_bounds__(WAVE) k_tail(const uint32_t* __restrict__ L, u
 // Lane l of block b sums points (b*64 + l) + j*64*gridDim.x, j < m, with mixed additions, then the
 // wave folds its 64 partial sums with shuffles.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_g1_sum(const uint8_t* __restrict__ pts, uint32_t n, uint32_t m, uint32_t* __restrict__ part) {
+__global__ void __launch_bounds__(WAVE, 2) k_g1_sum(const uint8_t* __restrict__ pts, uint32_t n, uint32_t m, uint32_t* __restrict__ part) {
     uint32_t lane0 = blockIdx.x * WAVE + threadIdx.x, strideL = gridDim.x * WAVE;
     g1_jac acc = jac_inf<fp>();
     for (uint32_t j = 0; j < m; j++) {
@@ -1086,7 +1058,7 @@ __global__ void __launch_bounds__(WAVE) k_pip_convert(const uint8_t* __restrict_
 }
 // lane per (window, bucket); `order` lists the buckets so that a wave's lanes have similar counts
 template <class F>
-__global__ void __launch_bounds__(WAVE) k_pip_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
                                                      const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t cbk,
                                                      uint32_t total, uint4* __restrict__ buckets) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
@@ -1679,12 +1651,21 @@ static void host_combine_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
     }
 }
 
-// Miller lines of pairs 0 .. npairs-1: the 8-lanes-per-pair kernel while that does not take more waves than the chip has slots
-static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, hipStream_t st) {
-    if (c->coop && (npairs + 7) / 8 <= c->slots)
+// Miller lines of pairs 0 .. npairs-1 (the last `extra` of them are the bucket pairs of the signature side): the
+// 8-lanes-per-pair kernel while that does not take more waves than the chip has slots.  Whole-chip batches in latency mode
+// (coop): the tuple pairs fill the chip exactly, so the few extra pairs would be a second round of waves that takes as long as
+// the first (2.2 ms at 3 % occupancy); with 8 lanes per pair they take ~1 ms instead.  In throughput mode (several batches
+// in flight) that second round overlaps other batches' kernels and one lane per pair is the cheaper form.
+static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipStream_t st) {
+    if (c->coop && (npairs + 7) / 8 <= c->slots) {
         k_lines_coop<<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
-    else
+    } else if (c->coop && extra && extra < npairs && (extra + 7) / 8 <= c->slots) {
+        uint32_t main_pairs = npairs - extra;
+        k_lines<<<(main_pairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, main_pairs, c->stride, c->d_lines);
+        k_lines_coop<<<(extra + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, main_pairs, extra, c->stride, c->d_lines);
+    } else {
         k_lines<<<(npairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
+    }
 }
 
 // Enqueues everything up to the shard's committed state (d_states slot 0).  n = local tuple count.
@@ -1739,7 +1720,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         npairs = n32 + total;
         xpair = 0xffffffffu;
         HIPCHK(hipEventRecord(c->ev[4], st));
-        launch_lines(c, npairs, st);
+        launch_lines(c, npairs, total, st);
         HIPCHK(hipEventRecord(c->ev[5], st));
     } else {
         c->sig_c = 0;
@@ -1755,7 +1736,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         }
         HIPCHK(hipEventRecord(c->ev[4], st));
         // small batch: the one extra (AggrSign, -G1) pair is pair n; its lines are folded in by k_lineprod2
-        launch_lines(c, n32 + 1, st);
+        launch_lines(c, n32 + 1, 0, st);
         HIPCHK(hipEventRecord(c->ev[5], st));
         uint32_t nblk0 = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
         uint32_t m0 = (n32 + WAVE * nblk0 - 1) / (WAVE * nblk0);
@@ -1770,13 +1751,17 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
         if (m < 1) m = 1;
         nblk = (npairs + WAVE * m - 1) / (WAVE * m);
-        k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, 1);
+        // throughput mode: every lane hands its partial product to k_lineprod2 (68 waves fold 64 x nblk partials per step: least
+        // total work); latency mode: the in-wave product tree runs in k_lineprod's 1020 waves (+6 Fp12 products per wave) and
+        // k_lineprod2 only folds nblk partials per step (one caller: 1.8 -> 0.4 ms)
+        int per_lane = c->coop ? 0 : 1;
+        k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, per_lane);
         HIPCHK(hipEventRecord(c->ev_lp, st));
-        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk * WAVE, c->d_lines, c->stride, xpair, c->d_L);
+        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, per_lane ? nblk * WAVE : nblk, c->d_lines, c->stride, xpair, c->d_L);
     }
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[7], st));
     HIPCHK(hipGetLastError());
     c->last_n = n;
@@ -1809,7 +1794,7 @@ static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, con
     uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
     int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
     if (rc) return rc;
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[8], st));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 8, hipMemcpyDeviceToHost, st));
     c->pending = true;
@@ -1920,7 +1905,7 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
     if (!c || !fp12s || kk == 0 || kk > 64) return MI355_BLS_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_states, fp12s, kk * 576, hipMemcpyHostToDevice, nullptr));
-    k_tail<<<1, WAVE, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, TAIL_THREADS, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipGetLastError());
     uint32_t v = 0;
     HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
@@ -1950,7 +1935,7 @@ extern "C" int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* c, const
     }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
+    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
                                (uint32_t)(stride_bytes / 4), 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_flags + 3, c->d_flags + 3, 4, hipMemcpyDeviceToHost, st));
@@ -2191,12 +2176,12 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     k_hash_one<<<1, WAVE, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
     k_fav_setup<<<1, 1, 0, st>>>(c->d_agg1, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
-    launch_lines(c, 2, st);
+    launch_lines(c, 2, 0, st);
     HIPCHK(hipEventRecord(c->ev[3], st));
     k_lineprod<<<dim3(N_LINES, 1), WAVE, 0, st>>>(c->d_lines, 2, c->stride, 1, c->d_lpart, 1, 0);
     k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_lines, c->stride, 0xffffffffu, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     uint32_t fl[2];
     HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
@@ -2665,7 +2650,7 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_aggv_setup<<<nb1, WAVE, 0, st>>>(d_pk, n32, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
-    launch_lines(c, n32 + 1, st);
+    launch_lines(c, n32 + 1, 0, st);
     HIPCHK(hipEventRecord(c->ev[3], st));
     uint32_t np = n32 + 1, nblk = c->slots / N_LINES;
     if (nblk < 1) nblk = 1;
@@ -2676,7 +2661,7 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, np, c->stride, mm, c->d_lpart, nblk, 0);
     k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, 0xffffffffu, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, WAVE, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipGetLastError());
     uint32_t fl[2];

@@ -274,3 +274,29 @@ def test_uncompressed_deserialisation(emu):
     assert emu.emu_g2_deserialize(bytes([0x40]) + bytes(191), out2, ctypes.byref(inf)) == 1 and inf.value == 1
     assert emu.emu_g2_deserialize(bytes([0x60]) + bytes(191), out2, ctypes.byref(inf)) == 0
     assert emu.emu_g1_deserialize(o.P.to_bytes(48, "big") + bytes(48), out, ctypes.byref(inf)) == 0
+
+
+def test_lane_cooperative_fp12_engine(emu):
+    """k_tail's Fp12 product / square (c12.hpp: 108 or 63 one-multiplication items, 168 limb-combination items, 12 reductions)
+    executed item by item on the CPU, bounds tracked, against the tower's fp12_mul and the big-int oracle; a chain of
+    squarings and products keeps the bounds."""
+    from util import fp12_to_bytes
+    rng = random.Random(12)
+
+    def rnd12():
+        return tuple((rng.randrange(o.P), rng.randrange(o.P)) for _ in range(6))
+    for _ in range(3):
+        a, b = rnd12(), rnd12()
+        A, B = fp12_to_bytes(a), fp12_to_bytes(b)
+        got = call(emu, "emu_c12_mul", A, B, outlen=576)
+        assert got == call(emu, "emu_fp12_mul", A, B, outlen=576)
+        assert fp12_from_bytes(got) == o.f12mul(a, b)
+        assert fp12_from_bytes(call(emu, "emu_c12_sqr", A, outlen=576)) == o.f12sqr(a)
+    x = fp12_to_bytes(rnd12())
+    want = fp12_from_bytes(x)
+    for i in range(6):
+        x = call(emu, "emu_c12_sqr", x, outlen=576)
+        want = o.f12sqr(want)
+        y = call(emu, "emu_c12_mul", x, x, outlen=576)
+        assert fp12_from_bytes(y) == o.f12sqr(want)
+    assert fp12_from_bytes(x) == want
