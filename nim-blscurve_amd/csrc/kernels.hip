@@ -7,9 +7,8 @@
 //   k_hash_clear  one lane per tuple: sum of the two mapped points, cofactor clearing; Jacobian H_i
 //   k_pkmul       one lane per tuple: [r_i]PK_i (signed 4-bit windows), Jacobian; infinity-pk flag (blst pk part)
 //   signature side (blst sig part + finalverify's extra pair):
-//     n >= 64:   k_sig_convert, k_msm_hist/scan/scatter (counting sort by digit of r_i), k_sig_bucket: bucket
-//                sums B_{w,d} -> extra Miller pairs (-[d 2^(cw)]G1, B_{w,d})
-//     n <  64:   k_sigmul ([r_i]S_i, wave-shuffle sum) + k_sigsum -> AggrSign, appended as pair n with P = -G1
+//     k_sig_convert, k_msm_hist/scan/scatter (counting sort by digit of r_i), k_sig_bucket: bucket
+//     sums B_{w,d} -> extra Miller pairs (-[d 2^(cw)]G1, B_{w,d})
 //   k_lines       one lane per pair: 68 Miller lines -> HBM, step-major SoA             (miller_loop_n)
 //   k_lineprod    (step, pair-range) grid: per-lane sparse products, wave-shuffle Fp12 product tree
 //   k_lineprod2   per step: product of the range partials -> L_s
@@ -375,55 +374,6 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
     soa_st_g1(P, stride, i, q);
 }
 
-// points are blst_p2_affine images at base + i*stride + offset (SignatureSet records: stride 320, offset 128)
-__global__ void __launch_bounds__(WAVE) k_sigmul(const uint8_t* __restrict__ sets, size_t stride_b, size_t offset_b, uint32_t n, const uint64_t* __restrict__ r,
-                                                 uint32_t* __restrict__ part) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    g2_jac acc = jac_inf<fp2>();
-    if (i < n) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * stride_b + offset_b);
-        g2_aff s = ld_g2a_blst(w);
-        acc = jac_mul_u64_w4(s, r[i]);              // infinity signature -> infinity (contributes nothing)
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        g2_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
-    }
-    if (threadIdx.x == 0) {
-        st_g2_int(part + (size_t)blockIdx.x * G2W, acc);
-    }
-}
-
-// level 1 of the partial-sum reduction: block b folds partials b, b+gridDim.x, ... -> part2[b]
-__global__ void __launch_bounds__(WAVE) k_sigsum1(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ part2) {
-    g2_jac acc = jac_inf<fp2>();
-    for (uint32_t j = blockIdx.x * WAVE + threadIdx.x; j < nparts; j += WAVE * gridDim.x) acc = jac_add(acc, ld_g2_int(part + (size_t)j * G2W));
-    for (int d = 32; d >= 1; d >>= 1) {
-        g2_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
-    }
-    if (threadIdx.x == 0) {
-        st_g2_int(part2 + (size_t)blockIdx.x * G2W, acc);
-    }
-}
-
-// one wave: sum of the partials -> AggrSign; stored as Q of pair `slot` with P = -G1 (affine, Z = 1)
-__global__ void __launch_bounds__(WAVE) k_sigsum(const uint32_t* __restrict__ part, uint32_t nparts, uint4* __restrict__ H, uint4* __restrict__ P,
-                                                 size_t stride, size_t slot, uint32_t* __restrict__ agg_out) {
-    g2_jac acc = jac_inf<fp2>();
-    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = jac_add(acc, ld_g2_int(part + (size_t)j * G2W));
-    for (int d = 32; d >= 1; d >>= 1) {
-        g2_jac o = shfl_down_struct(acc, d);
-        acc = jac_add(acc, o);
-    }
-    if (threadIdx.x == 0) {
-        soa_st_g2(H, stride, slot, acc);
-        g1_jac ng{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()};
-        soa_st_g1(P, stride, slot, ng);
-        st_g2_blst(agg_out, acc);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // k_lines_coop: the Miller lines of FEW pairs (up to 8 per wave): 8 lanes share one pair and split the independent
 // products of every doubling step (the 63 of the 68 steps): 5 squarings, then 2 squarings, then 2 products, then the
@@ -548,26 +498,24 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
         st_fp12_int(part + (((size_t)s * nblk + b) * WAVE + threadIdx.x) * F12W, f);
         return;
     }
-    for (int d = 32; d >= 1; d >>= 1) {
+    // lanes past the last pair of this range hold 1: skip the tree levels that would only fold ones (wave-uniform)
+    size_t live = first < npairs ? npairs - first : 0;
+    int top = 32;
+    while (top >= 1 && (size_t)top >= live) top >>= 1;
+    for (int d = top; d >= 1; d >>= 1) {
         fp12 o = shfl_down_struct(f, d);
         f = fp12_mul(f, o);
     }
     if (threadIdx.x == 0) st_fp12_int(part + ((size_t)s * nblk + b) * F12W, f);
 }
 
-// per step: product of the nblk range partials, times the line of the extra pair `xpair`
-// (small batches: the aggregated-signature pair)
-__global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__ part, uint32_t nblk, const uint4* __restrict__ lines, size_t stride,
-                                                    uint32_t xpair, uint32_t* __restrict__ L) {
+// per step: product of the nblk partials of k_lineprod -> L_s
+__global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__ part, uint32_t nblk, uint32_t* __restrict__ L) {
     uint32_t s = blockIdx.x;
     fp12 f = fp12_one();
-    if (threadIdx.x == 0 && xpair != 0xffffffffu) {
-        const uint4* base = lines + (size_t)s * 24 * stride;
-        f = fp12_from_line(line_t{soa_ld2(base, stride, 0, xpair), soa_ld2(base, stride, 2, xpair), soa_ld2(base, stride, 4, xpair)});
-    }
     for (uint32_t j = threadIdx.x; j < nblk; j += WAVE) {
         fp12 o = ld_fp12_int(part + ((size_t)s * nblk + j) * F12W);
-        f = (j < WAVE && !(threadIdx.x == 0 && xpair != 0xffffffffu)) ? o : fp12_mul(f, o);
+        f = j < WAVE ? o : fp12_mul(f, o);
     }
     int top = 32;                                   // lanes >= nblk hold 1: skip the tree levels that only fold ones
     while (top >= 1 && (uint32_t)top >= nblk) top >>= 1;
@@ -1455,6 +1403,7 @@ struct mi355_bls_ctx {
     bool coop = true;                // small batches: lane-cooperative kernels (latency) instead of one lane per item (throughput)
     bool wide_recorded = false;      // ev_lp (end of the whole-chip kernels) has been recorded at least once
     hipStream_t pending_stream = nullptr;
+    hipStream_t side = nullptr;      // fork / join stream of latency-mode calls (independent stages beside each other)
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
     hipEvent_t ev_hm = nullptr, ev_lp = nullptr;   // inside the hash stage (after k_hash_map) and the line-product stage (after k_lineprod)
@@ -1470,7 +1419,6 @@ struct mi355_bls_ctx {
 };
 
 constexpr uint32_t SIG_SLOTS_MAX = 2048;     // 8 windows x 256 digits
-constexpr size_t SIG_BUCKET_MIN = 64;        // below this the per-tuple 64-bit multiplications are cheaper than the 256 extra pairs
 constexpr size_t SIG_WIDE_MIN = 40000;       // from here 8-bit digits (2048 extra pairs, 8 additions per tuple) beat 4-bit ones (256, 15)
 
 static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
@@ -1484,6 +1432,7 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->side) (void)hipStreamDestroy(c->side);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_hm) (void)hipEventDestroy(c->ev_hm);
@@ -1545,6 +1494,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_flags, 16);
     ALLOC(c->d_export, c->stride * 288 + 2048 * 2 * G1W * 4);
 #undef ALLOC
+    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void**)&c->h_flags, 1024, hipHostMallocDefault));    // words 0..3 flags, 4..11 staging copy of rnd, 16..159 shard state
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreate(&c->ev_hm));
@@ -1659,7 +1609,9 @@ static void host_combine_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
 static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipStream_t st) {
     if (c->coop && (npairs + 7) / 8 <= c->slots) {
         k_lines_coop<<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
-    } else if (c->coop && extra && extra < npairs && (extra + 7) / 8 <= c->slots) {
+    } else if (c->coop && extra && extra < npairs && (extra + 7) / 8 <= c->slots &&
+               (npairs + WAVE - 1) / WAVE > c->slots * (((npairs - extra + WAVE - 1) / WAVE + c->slots - 1) / c->slots)) {
+        // the extra pairs would start one more round of waves: 8 lanes each instead
         uint32_t main_pairs = npairs - extra;
         k_lines<<<(main_pairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, main_pairs, c->stride, c->d_lines);
         k_lines_coop<<<(extra + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, main_pairs, extra, c->stride, c->d_lines);
@@ -1669,6 +1621,10 @@ static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipS
 }
 
 // Enqueues everything up to the shard's committed state (d_states slot 0).  n = local tuple count.
+// The three producers of Miller pairs are independent until the lines: hashing (k_hash_map, k_hash_clear), [r]PK (k_pkmul) and
+// the signature side (bucket fold).  A batch that fills the chip runs them one after the other on the caller's stream (each is a
+// whole-chip kernel).  A small batch in latency mode runs the last two on the context's side stream beside the hashing: they
+// are all latency-bound there (a few waves each), so this takes about a millisecond off the call.
 static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
                      size_t tuple_base, size_t n, int serial, const uint8_t rnd[32], hipStream_t st) {
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
@@ -1687,6 +1643,10 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, c->d_r);
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
+    const bool fork = c->coop && c->side && n32 <= 16 * c->slots;       // pk + signature side beside the hashing
+    hipStream_t sd = fork ? c->side : st;
+    if (fork) HIPCHK(hipStreamWaitEvent(sd, c->ev[1], 0));
+    // ---- hashing (caller's stream)
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
     if (c->coop && (n32 + 7) / 8 <= c->slots)
@@ -1694,71 +1654,51 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     else
         k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));
-    k_pkmul<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
-    HIPCHK(hipEventRecord(c->ev[3], st));
-    uint32_t nblk_max = c->slots / N_LINES, npairs = n32, xpair = n32;
-    if (n >= SIG_BUCKET_MIN) {
-        // bucket fold: the signature side becomes sig_slots extra Miller pairs n .. n + sig_slots - 1
-        uint32_t cw = n >= SIG_WIDE_MIN ? 8 : 4, nwin = 64 / cw, total = nwin << cw;
+    // ---- [r]PK
+    k_pkmul<<<nb, WAVE, 0, sd>>>(d_sets, n32, c->d_r, c->d_P, c->stride, c->d_flags);
+    HIPCHK(hipEventRecord(c->ev[3], sd));
+    // ---- signature side as a bucket fold: sig_slots extra Miller pairs n .. n + sig_slots - 1 (every batch size: for a
+    // handful of tuples the 256 nearly empty buckets are still cheaper than one 64-bit G2 multiplication per tuple, which is a
+    // 3 ms chain of doublings when nothing hides its latency)
+    uint32_t cw = n >= SIG_WIDE_MIN ? 8 : 4, nwin = 64 / cw, total = nwin << cw;
+    {
         msm_win W{nwin, cw, 0};
         uint32_t *hist = c->d_sig_hist, *offs = hist + SIG_SLOTS_MAX, *cursor = offs + SIG_SLOTS_MAX;
-        HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, st));
-        k_sig_convert<<<nb, WAVE, 0, st>>>(d_sets, n32, c->d_sig_pts);
-        k_msm_hist<<<dim3(nb, nwin), WAVE, 0, st>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
-        k_msm_scan<<<nwin, WAVE, 0, st>>>(hist, cw, offs, cursor);
-        k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, st>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
+        HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, sd));
+        k_sig_convert<<<nb, WAVE, 0, sd>>>(d_sets, n32, c->d_sig_pts);
+        k_msm_hist<<<dim3(nb, nwin), WAVE, 0, sd>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
+        k_msm_scan<<<nwin, WAVE, 0, sd>>>(hist, cw, offs, cursor);
+        k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, sd>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
         uint32_t per = n32 >> cw, lshift = 0;                          // expected entries per bucket; ~16 per lane
         while (lshift < 6 && (per >> (lshift + 1)) >= 16) lshift++;
         // small batches leave most of the chip idle: more lanes per bucket (down to ~2 entries per lane) shorten the kernel
         while (lshift < 6 && ((total << (lshift + 1)) <= 16 * c->slots) && (per >> (lshift + 1)) >= 2) lshift++;
-        k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
+        k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, sd>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
                                                                              c->d_sig_consts + (cw == 8 ? (size_t)SIG_SLOTS_MAX * G1W : 0), c->d_H, c->d_P,
                                                                              c->stride);
         c->sig_c = cw;
         c->sig_slots = total;
         c->agg_valid = false;
-        npairs = n32 + total;
-        xpair = 0xffffffffu;
-        HIPCHK(hipEventRecord(c->ev[4], st));
-        launch_lines(c, npairs, total, st);
-        HIPCHK(hipEventRecord(c->ev[5], st));
-    } else {
-        c->sig_c = 0;
-        c->sig_slots = 0;
-        c->agg_valid = true;
-        k_sigmul<<<nb, WAVE, 0, st>>>(d_sets, 320, 128, n32, c->d_r, c->d_spart);
-        if (nb > 64) {          // two-level fold: 16 waves, then one
-            uint32_t* part2 = c->d_spart + (size_t)nb * G2W;
-            k_sigsum1<<<16, WAVE, 0, st>>>(c->d_spart, nb, part2);
-            k_sigsum<<<1, WAVE, 0, st>>>(part2, 16, c->d_H, c->d_P, c->stride, n, c->d_agg);
-        } else {
-            k_sigsum<<<1, WAVE, 0, st>>>(c->d_spart, nb, c->d_H, c->d_P, c->stride, n, c->d_agg);
-        }
-        HIPCHK(hipEventRecord(c->ev[4], st));
-        // small batch: the one extra (AggrSign, -G1) pair is pair n; its lines are folded in by k_lineprod2
-        launch_lines(c, n32 + 1, 0, st);
-        HIPCHK(hipEventRecord(c->ev[5], st));
-        uint32_t nblk0 = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
-        uint32_t m0 = (n32 + WAVE * nblk0 - 1) / (WAVE * nblk0);
-        if (m0 < 1) m0 = 1;
-        nblk0 = (n32 + WAVE * m0 - 1) / (WAVE * m0);
-        k_lineprod<<<dim3(N_LINES, nblk0), WAVE, 0, st>>>(c->d_lines, n32, c->stride, m0, c->d_lpart, nblk0, 0);
-        HIPCHK(hipEventRecord(c->ev_lp, st));
-        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk0, c->d_lines, c->stride, xpair, c->d_L);
     }
-    if (xpair == 0xffffffffu) {
-        uint32_t nblk = nblk_max < 1 ? 1 : (nblk_max > c->nblk_cap ? c->nblk_cap : nblk_max);
-        uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
-        if (m < 1) m = 1;
-        nblk = (npairs + WAVE * m - 1) / (WAVE * m);
-        // throughput mode: every lane hands its partial product to k_lineprod2 (68 waves fold 64 x nblk partials per step: least
-        // total work); latency mode: the in-wave product tree runs in k_lineprod's 1020 waves (+6 Fp12 products per wave) and
-        // k_lineprod2 only folds nblk partials per step (one caller: 1.8 -> 0.4 ms)
-        int per_lane = c->coop ? 0 : 1;
-        k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, per_lane);
-        HIPCHK(hipEventRecord(c->ev_lp, st));
-        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, per_lane ? nblk * WAVE : nblk, c->d_lines, c->stride, xpair, c->d_L);
-    }
+    HIPCHK(hipEventRecord(c->ev[4], sd));
+    if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));              // join
+    // ---- Miller lines and their products per step
+    uint32_t npairs = n32 + total;
+    launch_lines(c, npairs, total, st);
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    uint32_t nblk = c->slots / N_LINES;
+    if (nblk < 1) nblk = 1;
+    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
+    uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
+    if (m < 1) m = 1;
+    nblk = (npairs + WAVE * m - 1) / (WAVE * m);
+    // throughput mode: every lane hands its partial product to k_lineprod2 (68 waves fold 64 x nblk partials per step: least
+    // total work); latency mode: the in-wave product tree runs in k_lineprod's waves (+6 Fp12 products per wave) and
+    // k_lineprod2 only folds nblk partials per step (one caller, 65 536 tuples: 1.8 -> 0.4 ms)
+    int per_lane = c->coop ? 0 : 1;
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, per_lane);
+    HIPCHK(hipEventRecord(c->ev_lp, st));
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, per_lane ? nblk * WAVE : nblk, c->d_L);
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
     k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
@@ -1778,7 +1718,10 @@ static int collect_timings(mi355_bls_ctx* c, int last_ev) {
         HIPCHK(hipEventElapsedTime(&c->ktimes[2], c->ev[5], c->ev_lp));
         HIPCHK(hipEventElapsedTime(&c->ktimes[3], c->ev_lp, c->ev[6]));
     }
-    for (int i = 0; i < last_ev; i++) HIPCHK(hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]));
+    for (int i = 0; i < last_ev; i++) {
+        HIPCHK(hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]));
+        if (c->timings[i] < 0) c->timings[i] = 0;              // stages that ran side by side on the fork stream
+    }
     HIPCHK(hipEventElapsedTime(&c->timings[7], c->ev[0], c->ev[last_ev]));
     return 0;
 }
@@ -2170,16 +2113,20 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     HIPCHK(hipMemcpyAsync(c->d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
-    int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, st);
+    // the key sum and the hash of the message are independent: side by side in latency mode
+    hipStream_t sd = (c->coop && c->side) ? c->side : st;
+    if (sd != st) HIPCHK(hipStreamWaitEvent(sd, c->ev[0], 0));
+    int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, sd);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipEventRecord(c->ev[1], sd));
     k_hash_one<<<1, WAVE, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
+    if (sd != st) HIPCHK(hipStreamWaitEvent(st, c->ev[1], 0));
     k_fav_setup<<<1, 1, 0, st>>>(c->d_agg1, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
     launch_lines(c, 2, 0, st);
     HIPCHK(hipEventRecord(c->ev[3], st));
     k_lineprod<<<dim3(N_LINES, 1), WAVE, 0, st>>>(c->d_lines, 2, c->stride, 1, c->d_lpart, 1, 0);
-    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_lines, c->stride, 0xffffffffu, c->d_L);
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
     k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
@@ -2659,7 +2606,7 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     if (mm < 1) mm = 1;
     nblk = (np + WAVE * mm - 1) / (WAVE * mm);
     k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, np, c->stride, mm, c->d_lpart, nblk, 0);
-    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_lines, c->stride, 0xffffffffu, c->d_L);
+    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
     k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
