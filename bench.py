@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="batches kept in flight per GPU (independent caller contexts)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the fastAggregateVerify / MSM / small-batch side measurements")
+    ap.add_argument("--ctx-mode", choices=["auto", "latency", "throughput"], default="auto",
+                    help="mode of the contexts of the timed region (mi355_bls_ctx_set_cooperative): auto = throughput when several batches are in flight")
+    ap.add_argument("--no-one-caller", action="store_true", help="skip the one-blocking-caller measurements after the timed region (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (shards + collective) even with one rank")
     ap.add_argument("--exchange", choices=["device", "host"], default=os.environ.get("BENCH_EXCHANGE", "device"),
                     help="N > 1: all_gather of device-resident shard blobs (RCCL, no host round trip) or of host bytes")
@@ -104,9 +107,9 @@ def main():
     # bls_batch_verifier.nim:389-391) keep several batches in flight so that one batch's serial tail
     # (step products, Horner, final exponentiation: a handful of waves) overlaps another batch's wide kernels.
     caches = [m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local) for _ in range(inflight)]
-    if inflight > 1:
-        for c in caches:
-            c.set_cooperative(False)            # throughput mode: several batches in flight (include/blscurve_mi355x.h)
+    throughput_mode = a.ctx_mode == "throughput" or (a.ctx_mode == "auto" and inflight > 1)
+    for c in caches:
+        c.set_cooperative(not throughput_mode)  # throughput mode: several batches in flight (include/blscurve_mi355x.h)
     cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)      # the one blocking caller: latency mode
     fv_caches = [m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=nthreads, device=local) for _ in range(inflight)] if sharded_path else []
     lo, hi, first, count = m.shard_plan(n_total, nthreads, world, rank)
@@ -265,7 +268,11 @@ def main():
         timed_kernel_ms = {k: v for k, v in all_ms.items() if k.startswith("k_") and k in KERNEL_BYTES}
         timed_kernel_ms.update({KERNEL_OF_STAGE[k]: v for k, v in stage_ms.items() if k in KERNEL_OF_STAGE})
         # ---- outside the timed region: ONE caller, un-overlapped (kernel-alone durations, single-caller rate, PCIe-inclusive rate)
-        one = one_caller_rows(m, cache, streams[0], d_sets, n, n_total, lo, hi, rnd, sharded_path)
+        if a.no_one_caller:
+            one = {"kernel_alone_ms": {**timed_kernel_ms, "k_sig_bucket": stage_ms.get("sig_mul_sum", 0.0)}, "tail_ms_alone": {}, "value_one_caller": None,
+                   "ms_one_caller": None}
+        else:
+            one = one_caller_rows(m, cache, streams[0], d_sets, n, n_total, lo, hi, rnd, sharded_path)
         alone = one["kernel_alone_ms"]
         dom = max(alone, key=lambda k: alone[k])                   # the dominant single kernel, by its un-overlapped duration
         alg_bytes = KERNEL_BYTES[dom] * n
@@ -291,6 +298,7 @@ def main():
                     "rnd=SHA256('Mr F was here'), resident in HBM" % n,
             "config": {"workload": "BatchedBLSVerifier batchVerify, %d-tuple batch per GPU" % n, "global_batch": n_total,
                        "blinding_chains": nthreads, "parallelism": "shard%d" % world, "batches_in_flight": inflight,
+                       "context_mode": "throughput" if throughput_mode else "latency",
                        "exchange": exchange if sharded_path else None},
             "value_one_caller": one["value_one_caller"],
             "ms_one_caller": one["ms_one_caller"],

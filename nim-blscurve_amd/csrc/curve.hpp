@@ -98,6 +98,37 @@ BLS_MID jac<F> jac_dbl(const jac<F>& p) {
     return r;
 }
 
+// Lane-cooperative doubling for latency-bound chains (one point, or a few, and a whole wave to spend): a TEAM of lanes that all
+// hold the same point computes the independent products of each round of dbl-2009-l in ONE multiplier call, every lane taking
+// one of them, and shares the results.  The formula, its carries and its reductions are jac_dbl's; only who multiplies differs,
+// and that is the Team's business: team_solo (below; host tests and the bounds tracker) computes every product itself, the
+// device teams of kernels.hip select an operand pair by role and broadcast the results with wave shuffles.
+struct team_solo {
+    template <class F>
+    BLS_HD void mul3(F& r0, F& r1, F& r2, const F& a0, const F& b0, const F& a1, const F& b1, const F& a2, const F& b2) const {
+        r0 = f_mul(a0, b0); r1 = f_mul(a1, b1); r2 = f_mul(a2, b2);
+    }
+    template <class F>
+    BLS_HD void sqr3(F& r0, F& r1, F& r2, const F& a0, const F& a1, const F& a2) const {
+        r0 = f_sqr(a0); r1 = f_sqr(a1); r2 = f_sqr(a2);
+    }
+};
+template <class F, class Team>
+BLS_MID jac<F> jac_dbl_team(const jac<F>& p, const Team& team) {
+    F A, B, YZ;
+    team.mul3(A, B, YZ, p.x, p.x, p.y, p.y, p.y, p.z);                               // X^2 | Y^2 | Y Z
+    F E = f_carry(f_add_nc(f_dbl_nc(A), A));
+    F C, t, Fq;
+    team.sqr3(C, t, Fq, B, f_add(p.x, B), E);                                        // B^2 | (X+B)^2 | E^2
+    F D = f_carry(f_dbl_nc(f_sub_nc(f_sub_nc(t, A), C)));
+    jac<F> r;
+    r.x = f_red(f_sub_nc(Fq, f_dbl_nc(D)));
+    F C8 = f_dbl_nc(f_carry(f_dbl_nc(f_dbl_nc(C))));
+    r.y = f_carry(f_sub_nc(f_mul(E, f_sub_nc(D, r.x)), C8));
+    r.z = f_carry(f_dbl_nc(YZ));
+    return r;
+}
+
 // Jacobian + affine, complete (handles infinity operands, P == Q, P == -Q).
 template <class F>
 BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {

@@ -302,20 +302,40 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
 // (3 multiplication times per doubling instead of 7).  Every lane holds the same points throughout.
 // lane-parallel jac_dbl inside a group of 8 lanes that all hold the same point (same formulas, carries and
 // reductions as curve.hpp's): roles 0..2 take the three independent products of each of the first two rounds
-__device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
-    fp2 r1 = fp2_mul(fp2_select(role == 0, p.x, p.y), fp2_select(role == 0, p.x, fp2_select(role == 1, p.y, p.z)));        // X^2 | Y^2 | Y Z
-    fp2 A = fp2_from_role(r1, gbase, 0), B = fp2_from_role(r1, gbase, 1), YZ = fp2_from_role(r1, gbase, 2);
-    fp2 E = fp2_carry(fp2_add_nc(fp2_dbl_nc(A), A));
-    fp2 r2 = fp2_sqr(fp2_select(role == 0, B, fp2_select(role == 1, fp2_add(p.x, B), E)));                                 // B^2 | (X+B)^2 | E^2
-    fp2 C = fp2_from_role(r2, gbase, 0), t = fp2_from_role(r2, gbase, 1), Fq = fp2_from_role(r2, gbase, 2);
-    fp2 D = fp2_carry(fp2_dbl_nc(fp2_sub_nc(fp2_sub_nc(t, A), C)));
-    g2_jac r;
-    r.x = fp2_reduce(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
-    fp2 C8 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_dbl_nc(C))));
-    r.y = fp2_carry(fp2_sub_nc(fp2_mul(E, fp2_sub_nc(D, r.x)), C8));
-    r.z = fp2_carry(fp2_dbl_nc(YZ));
-    return r;
-}
+// device teams: lanes gbase .. gbase + 7 hold the same values; roles 0.. take one product each of a round (ONE multiplier call
+// with per-lane operands), then every lane reads all results with wave shuffles.  Formulas: jac_dbl_team / miller_dbl_step_team.
+struct team_lanes8 {
+    uint32_t gbase, role;
+    __device__ __forceinline__ void mul3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2) const {
+        fp2 r = fp2_mul(fp2_select(role == 0, a0, fp2_select(role == 1, a1, a2)), fp2_select(role == 0, b0, fp2_select(role == 1, b1, b2)));
+        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
+    }
+    __device__ __forceinline__ void sqr3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& a1, const fp2& a2) const {
+        fp2 r = fp2_sqr(fp2_select(role == 0, a0, fp2_select(role == 1, a1, a2)));
+        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
+    }
+    __device__ __forceinline__ void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
+        fp2 r = fp2_sqr(fp2_select(role == 0, a0, fp2_select(role == 1, a1, fp2_select(role == 2, a2, fp2_select(role == 3, a3, a4)))));
+        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
+        r3 = fp2_from_role(r, gbase, 3); r4 = fp2_from_role(r, gbase, 4);
+    }
+    __device__ __forceinline__ void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const {
+        fp2 r = fp2_sqr(fp2_select(role == 0, a0, a1));
+        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1);
+    }
+    __device__ __forceinline__ void mul2(fp2& r0, fp2& r1, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1) const {
+        fp2 r = fp2_mul(fp2_select(role == 0, a0, a1), fp2_select(role == 0, b0, b1));
+        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1);
+    }
+    __device__ __forceinline__ void fpmul6(fp (&r)[6], const fp (&a)[6], const fp (&b)[3]) const {
+        fp xa = fp_select(role == 0, a[0], fp_select(role == 1, a[1], fp_select(role == 2, a[2], fp_select(role == 3, a[3], fp_select(role == 4, a[4], a[5])))));
+        fp xb = fp_select(role < 2, b[0], fp_select(role < 4, b[1], b[2]));
+        fp v = fp_mul(xa, xb);
+#pragma unroll
+        for (int i = 0; i < 6; i++) r[i] = fp_from_role(v, gbase, (uint32_t)i);
+    }
+};
+__device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return jac_dbl_team(p, team_lanes8{gbase, role}); }
 __device__ g2_jac g2_mul_x_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
     g2_jac acc = jac_inf<fp2>();
 #pragma clang loop unroll(disable)
@@ -382,34 +402,7 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
 // redundantly in every lane.  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.9 ms).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ line_t miller_dbl_step_coop(g2_proj& t, const g1_pre& p, uint32_t gbase, uint32_t role) {
-    // round 1: B = Y^2 | C = Z^2 | X^2 | (Y+Z)^2 | (X+Y)^2
-    fp2 YZs = fp2_add(t.y, t.z), XYs = fp2_add(t.x, t.y);
-    fp2 a1 = fp2_select(role == 0, t.y, fp2_select(role == 1, t.z, fp2_select(role == 2, t.x, fp2_select(role == 3, YZs, XYs))));
-    fp2 r1 = fp2_sqr(a1);
-    fp2 B = fp2_from_role(r1, gbase, 0), C = fp2_from_role(r1, gbase, 1), X2 = fp2_from_role(r1, gbase, 2);
-    fp2 S1 = fp2_from_role(r1, gbase, 3), S2 = fp2_from_role(r1, gbase, 4);
-    fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));
-    fp2 E = fp2_reduce(fp2_add_nc(fp2_dbl_nc(C4), C4));
-    fp2 F = fp2_add_nc(fp2_dbl_nc(E), E);
-    fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(S1, B), C));
-    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(S2, X2), B));
-    // round 2: E^2 | (B + F)^2
-    fp2 r2 = fp2_sqr(fp2_select(role == 0, E, fp2_carry(fp2_add_nc(B, F))));
-    fp2 E2 = fp2_from_role(r2, gbase, 0), S = fp2_from_role(r2, gbase, 1);
-    fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
-    // round 3: XY2 (B - F) | B H
-    fp2 r3 = fp2_mul(fp2_select(role == 0, XY2, B), fp2_select(role == 0, fp2_carry(fp2_sub_nc(B, F)), H));
-    fp2 x3 = fp2_from_role(r3, gbase, 0), BH = fp2_from_role(r3, gbase, 1);
-    fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));
-    fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(BH)));
-    t = g2_proj{x3, y3, z3};
-    // line scaling: (B - E).c0 z3 | (B - E).c1 z3 | X2.c0 nxz3 | X2.c1 nxz3 | H.c0 y | H.c1 y
-    fp2 BE = fp2_sub_nc(B, E);
-    fp xa = fp_select(role == 0, BE.c0, fp_select(role == 1, BE.c1, fp_select(role == 2, X2.c0, fp_select(role == 3, X2.c1, fp_select(role == 4, H.c0, H.c1)))));
-    fp xb = fp_select(role < 2, p.z3, fp_select(role < 4, p.nxz3, p.y));
-    fp r4 = fp_mul(xa, xb);
-    return line_t{fp2{fp_from_role(r4, gbase, 0), fp_from_role(r4, gbase, 1)}, fp2{fp_from_role(r4, gbase, 2), fp_from_role(r4, gbase, 3)},
-                  fp2{fp_from_role(r4, gbase, 4), fp_from_role(r4, gbase, 5)}};
+    return miller_dbl_step_team(t, p, team_lanes8{gbase, role});
 }
 __global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
                                                      uint4* __restrict__ lines) {
@@ -1068,21 +1061,19 @@ __device__ __forceinline__ fp fp_bcast(const fp& a, int src) {
     for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
     return r;
 }
-__device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) {
-    const uint32_t l = threadIdx.x;
-    fp r1 = fp_mul(fp_select(l == 0, p.x, p.y), fp_select(l == 0, p.x, fp_select(l == 1, p.y, p.z)));      // X^2 | Y^2 | Y Z
-    fp A = fp_bcast(r1, 0), B = fp_bcast(r1, 1), YZ = fp_bcast(r1, 2);
-    fp E = fp_carry(fp_add_nc(fp_dbl_nc(A), A));
-    fp r2 = fp_sqr(fp_select(l == 0, B, fp_select(l == 1, fp_add(p.x, B), E)));                             // B^2 | (X+B)^2 | E^2
-    fp C = fp_bcast(r2, 0), t = fp_bcast(r2, 1), Fq = fp_bcast(r2, 2);
-    fp D = fp_carry(fp_dbl_nc(fp_sub_nc(fp_sub_nc(t, A), C)));
-    g1_jac r;
-    r.x = fp_reduce(fp_sub_nc(Fq, fp_dbl_nc(D)));
-    fp C8 = fp_dbl_nc(fp_carry(fp_dbl_nc(fp_dbl_nc(C))));
-    r.y = fp_carry(fp_sub_nc(fp_mul(E, fp_sub_nc(D, r.x)), C8));
-    r.z = fp_carry(fp_dbl_nc(YZ));
-    return r;
-}
+struct team_wave_fp {               // every lane of the wave holds the same point; lanes 0, 1, 2 take the products
+    __device__ __forceinline__ void mul3(fp& r0, fp& r1, fp& r2, const fp& a0, const fp& b0, const fp& a1, const fp& b1, const fp& a2, const fp& b2) const {
+        const uint32_t l = threadIdx.x;
+        fp r = fp_mul(fp_select(l == 0, a0, fp_select(l == 1, a1, a2)), fp_select(l == 0, b0, fp_select(l == 1, b1, b2)));
+        r0 = fp_bcast(r, 0); r1 = fp_bcast(r, 1); r2 = fp_bcast(r, 2);
+    }
+    __device__ __forceinline__ void sqr3(fp& r0, fp& r1, fp& r2, const fp& a0, const fp& a1, const fp& a2) const {
+        const uint32_t l = threadIdx.x;
+        fp r = fp_sqr(fp_select(l == 0, a0, fp_select(l == 1, a1, a2)));
+        r0 = fp_bcast(r, 0); r1 = fp_bcast(r, 1); r2 = fp_bcast(r, 2);
+    }
+};
+__device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) { return jac_dbl_team(p, team_wave_fp{}); }
 __device__ __forceinline__ g1_jac dbl_coop(const g1_jac& p) { return g1_dbl_coop(p); }
 __device__ __forceinline__ g2_jac dbl_coop(const g2_jac& p) { return g2_dbl_coop(p, threadIdx.x & ~7u, threadIdx.x & 7u); }
 __device__ __forceinline__ g1_jac bcast0(const g1_jac& a) { return g1_jac{fp_bcast(a.x, 0), fp_bcast(a.y, 0), fp_bcast(a.z, 0)}; }

@@ -300,3 +300,21 @@ def test_lane_cooperative_fp12_engine(emu):
         y = call(emu, "emu_c12_mul", x, x, outlen=576)
         assert fp12_from_bytes(y) == o.f12sqr(want)
     assert fp12_from_bytes(x) == want
+
+
+def test_team_formulas_equal_the_plain_ones(emu):
+    """jac_dbl_team / miller_dbl_step_team (the lane-cooperative kernels' formulas, curve.hpp / pairing.hpp) with the solo team,
+    bounds tracked: same points as jac_dbl, same 68 lines as miller_lines."""
+    rng = random.Random(21)
+    for _ in range(3):
+        p = o.g1_mul(o.G1_GEN, rng.randrange(1, o.R))
+        q = o.g2_mul(o.G2_GEN, rng.randrange(1, o.R))
+        P, Q = g1_aff_to_jac_bytes(p), g2_aff_to_jac_bytes(q)
+        for _ in range(3):                                   # a few doublings deep: non-trivial Z
+            a, b = call(emu, "emu_g2_dbl_team", Q, outlen=288), call(emu, "emu_g2_dbl", Q, outlen=288)
+            assert g2_jac_to_affine(a) == g2_jac_to_affine(b) == o.g2_add(g2_jac_to_affine(Q), g2_jac_to_affine(Q))
+            Q = a
+            a, b = call(emu, "emu_g1_dbl_team", P, outlen=144), call(emu, "emu_g1_dbl", P, outlen=144)
+            assert g1_jac_to_affine(a) == g1_jac_to_affine(b)
+            P = a
+        assert emu.emu_miller_lines_team_equal(P, Q) == 1

@@ -10,6 +10,13 @@ import json
 import re
 import sys
 
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    from bench import KERNEL_BYTES, MAD_PER_TUPLE
+except Exception:                      # torch missing: the shares are simply not computed
+    KERNEL_BYTES, MAD_PER_TUPLE = {}, {}
+TUPLES = 65536
 out, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -30,6 +37,14 @@ for k, v in agg.items():
         e["hbm_bytes_corrected"] = 2 * f + w
     if "SQ_WAVE_CYCLES" in e and e.get("SQ_INSTS_VALU"):
         e["cycles_per_valu"] = 4 * e["SQ_WAVE_CYCLES"] / e["SQ_INSTS_VALU"]
+    if e.get("SQ_INSTS_VALU") and k in MAD_PER_TUPLE:
+        # 64-bit multiply-adds (census of the formulas, bench.py MAD_PER_TUPLE) as a share of all VALU wave-instructions:
+        # one wave-instruction serves 64 tuples (k_hash_map: two lanes per tuple, so 32)
+        waves_per_tuple = (1 / 32.0) if k == "k_hash_map" else (1 / 64.0)
+        e["mad_share_of_valu"] = MAD_PER_TUPLE[k] * TUPLES * waves_per_tuple / e["SQ_INSTS_VALU"] / (2 if k == "k_hash_map" else 1)
+        e["algorithmic_bytes"] = KERNEL_BYTES.get(k, 0) * TUPLES
+        if e.get("hbm_bytes_corrected") and e["algorithmic_bytes"]:
+            e["hbm_over_algorithmic"] = e["hbm_bytes_corrected"] / e["algorithmic_bytes"]
     res[k] = e
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, len(res), "kernels")
