@@ -112,6 +112,8 @@ struct team_solo {
     BLS_HD void sqr3(F& r0, F& r1, F& r2, const F& a0, const F& a1, const F& a2) const {
         r0 = f_sqr(a0); r1 = f_sqr(a1); r2 = f_sqr(a2);
     }
+    template <class F>
+    BLS_HD F mul1(const F& a, const F& b) const { return f_mul(a, b); }
 };
 template <class F, class Team>
 BLS_MID jac<F> jac_dbl_team(const jac<F>& p, const Team& team) {
@@ -124,7 +126,7 @@ BLS_MID jac<F> jac_dbl_team(const jac<F>& p, const Team& team) {
     jac<F> r;
     r.x = f_red(f_sub_nc(Fq, f_dbl_nc(D)));
     F C8 = f_dbl_nc(f_carry(f_dbl_nc(f_dbl_nc(C))));
-    r.y = f_carry(f_sub_nc(f_mul(E, f_sub_nc(D, r.x)), C8));
+    r.y = f_carry(f_sub_nc(team.mul1(E, f_sub_nc(D, r.x)), C8));
     r.z = f_carry(f_dbl_nc(YZ));
     return r;
 }

@@ -617,6 +617,24 @@ __device__ __noinline__ bls_u32x32 fp2_sqr_regs(uint32_t a0, uint32_t a1, uint32
     }
     return fp2_pack(fp_mul_core(sm, df), fp_mul_core(d0, x1));
 }
+// ONE lazily reduced dot product x0 y0 + x1 y1 (half an Fp2 product), (y0, y1) handed over through the LDS slot like the
+// second operand of fp2_mul_regs: what a lane of a cooperative team computes when an Fp2 product is split over two lanes.
+__device__ __noinline__ fp fp_dot2_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12, uint32_t a13, uint32_t a14, uint32_t a15, uint32_t a16, uint32_t a17, uint32_t a18, uint32_t a19, uint32_t a20, uint32_t a21, uint32_t a22, uint32_t a23, uint32_t a24, uint32_t a25, uint32_t a26, uint32_t a27, const bls_lds_u32x4* slot) {
+    fp x0{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}}, x1{{a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27}}, y0, y1;
+    uint32_t yw[28];
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        bls_u32x4 v = slot[q * 64 + lane];
+        yw[4 * q] = v.x; yw[4 * q + 1] = v.y; yw[4 * q + 2] = v.z; yw[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) {
+        y0.l[i] = yw[i];
+        y1.l[i] = yw[FP_N + i];
+    }
+    return fp_dot2_core(x0, y0, x1, y1);
+}
 #endif
 
 // Fp2 product: c0 = a0 b0 - a1 b1 and c1 = a0 b1 + a1 b0 as two lazily reduced dot products (4 operand products,
@@ -665,6 +683,12 @@ __device__ __forceinline__ fp2 fp2_lds_get(const bls_lds_u32x4* slot) {
 // a * (the Fp2 value parked in the LDS slot)
 __device__ __forceinline__ fp2 fp2_mul_lds(const fp2& a, const bls_lds_u32x4* slot) {
     return fp2_unpack(fp2_mul_regs(a.c0.l[0], a.c0.l[1], a.c0.l[2], a.c0.l[3], a.c0.l[4], a.c0.l[5], a.c0.l[6], a.c0.l[7], a.c0.l[8], a.c0.l[9], a.c0.l[10], a.c0.l[11], a.c0.l[12], a.c0.l[13], a.c1.l[0], a.c1.l[1], a.c1.l[2], a.c1.l[3], a.c1.l[4], a.c1.l[5], a.c1.l[6], a.c1.l[7], a.c1.l[8], a.c1.l[9], a.c1.l[10], a.c1.l[11], a.c1.l[12], a.c1.l[13], slot));
+}
+// x0 y0 + x1 y1
+__device__ __forceinline__ fp fp_dot2(const fp& x0, const fp& y0, const fp& x1, const fp& y1) {
+    bls_lds_u32x4* x = (bls_lds_u32x4*)bls_xchg;
+    fp2_lds_put(x, fp2{y0, y1});
+    return fp_dot2_regs(x0.l[0], x0.l[1], x0.l[2], x0.l[3], x0.l[4], x0.l[5], x0.l[6], x0.l[7], x0.l[8], x0.l[9], x0.l[10], x0.l[11], x0.l[12], x0.l[13], x1.l[0], x1.l[1], x1.l[2], x1.l[3], x1.l[4], x1.l[5], x1.l[6], x1.l[7], x1.l[8], x1.l[9], x1.l[10], x1.l[11], x1.l[12], x1.l[13], x);
 }
 __device__ __forceinline__ fp2 fp2_mul(const fp2& a, const fp2& b) {
     bls_lds_u32x4* x = (bls_lds_u32x4*)bls_xchg;

@@ -227,8 +227,9 @@ struct g2_park_regs {
 // written as ONE copy of the 63-doubling chain executed twice (pass 0: t1 = [x]P; pass 1: [x](t1 + psi(P))), with the chain's
 // accumulator a plain loop-carried value: inlined into the kernel it lives in registers for the whole chain (as the return
 // value of an out-of-line [x]-multiplication it lived in scratch memory and was stored back 84 words per doubling).
-template <class Park>
-BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
+// dbl: the doubling of the chain (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
+template <class Park, class Dbl>
+BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park, Dbl&& dbl) {
     g2_jac base = p, u = p, res = p;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < 2; pass++) {
@@ -236,13 +237,13 @@ BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
         g2_jac acc = base;                                   // bit 63 of |x|
 #pragma clang loop unroll(disable)
         for (int i = 62; i >= 0; i--) {
-            acc = jac_dbl(acc);
+            acc = dbl(acc);
             if ((k::X_ABS >> i) & 1) acc = jac_add_body(acc, park.get());
         }
         acc = jac_neg(acc);                                  // x < 0
         if (pass == 0) {
             g2_jac t2 = g2_psi(p);
-            u = jac_add(g2_psi(g2_psi(jac_dbl(p))), jac_neg(t2));        // psi^2(2P) - psi(P)
+            u = jac_add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));            // psi^2(2P) - psi(P)
             u = jac_add(u, jac_neg(acc));                                // - [x]P
             u = jac_add(u, jac_neg(p));                                  // - P
             base = jac_add(acc, t2);                                     // [x]P + psi(P)
@@ -251,6 +252,10 @@ BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
         }
     }
     return res;
+}
+template <class Park>
+BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
+    return clear_cofactor_g2_with(p, park, [](const g2_jac& a) { return jac_dbl(a); });
 }
 BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
     g2_park_regs park;

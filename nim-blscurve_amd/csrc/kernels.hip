@@ -306,26 +306,44 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
 // with per-lane operands), then every lane reads all results with wave shuffles.  Formulas: jac_dbl_team / miller_dbl_step_team.
 struct team_lanes8 {
     uint32_t gbase, role;
+    // An Fp2 product is two independent dot products, an Fp2 square two independent Fp products: SIX lanes take one HALF each
+    // (role r: product r / 2, real part for even r, imaginary for odd), so a round costs one Fp-sized multiplier call
+    // (~700 instructions) instead of an Fp2-sized one (~1400): the chain is latency-bound, the other lanes are idle anyway.
+    __device__ __forceinline__ fp2 pick3(const fp2& a0, const fp2& a1, const fp2& a2) const {
+        const uint32_t q = role >> 1;
+        return fp2_select(q == 0, a0, fp2_select(q == 1, a1, a2));
+    }
+    __device__ __forceinline__ fp2 gather3(const fp& v, uint32_t q) const { return fp2{fp_from_role(v, gbase, 2 * q), fp_from_role(v, gbase, 2 * q + 1)}; }
+    __device__ __forceinline__ fp half_mul(const fp2& a, const fp2& b) const {          // real (even role) or imaginary half of a * b
+        const bool im = (role & 1) != 0;
+        return fp_dot2(a.c0, fp_select(im, b.c1, b.c0), fp_select(im, a.c1, fp_neg(a.c1)), fp_select(im, b.c0, b.c1));
+    }
+    __device__ __forceinline__ fp half_sqr(const fp2& a) const {                        // (a0 + a1)(a0 - a1)  |  2 a0 a1
+        const bool im = (role & 1) != 0;
+        return fp_mul(fp_select(im, fp_dbl_nc(a.c0), fp_add_nc(a.c0, a.c1)), fp_select(im, a.c1, fp_sub_nc(a.c0, a.c1)));
+    }
     __device__ __forceinline__ void mul3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2) const {
-        fp2 r = fp2_mul(fp2_select(role == 0, a0, fp2_select(role == 1, a1, a2)), fp2_select(role == 0, b0, fp2_select(role == 1, b1, b2)));
-        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
+        fp v = half_mul(pick3(a0, a1, a2), pick3(b0, b1, b2));
+        r0 = gather3(v, 0); r1 = gather3(v, 1); r2 = gather3(v, 2);
     }
     __device__ __forceinline__ void sqr3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& a1, const fp2& a2) const {
-        fp2 r = fp2_sqr(fp2_select(role == 0, a0, fp2_select(role == 1, a1, a2)));
-        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
+        fp v = half_sqr(pick3(a0, a1, a2));
+        r0 = gather3(v, 0); r1 = gather3(v, 1); r2 = gather3(v, 2);
     }
+    __device__ __forceinline__ fp2 mul1(const fp2& a, const fp2& b) const { return gather3(half_mul(a, b), 0); }
     __device__ __forceinline__ void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
         fp2 r = fp2_sqr(fp2_select(role == 0, a0, fp2_select(role == 1, a1, fp2_select(role == 2, a2, fp2_select(role == 3, a3, a4)))));
         r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
         r3 = fp2_from_role(r, gbase, 3); r4 = fp2_from_role(r, gbase, 4);
     }
-    __device__ __forceinline__ void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const {
-        fp2 r = fp2_sqr(fp2_select(role == 0, a0, a1));
-        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1);
+    __device__ __forceinline__ void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const {      // four lanes, one half each
+        fp v = half_sqr(fp2_select((role >> 1) == 0, a0, a1));
+        r0 = gather3(v, 0); r1 = gather3(v, 1);
     }
     __device__ __forceinline__ void mul2(fp2& r0, fp2& r1, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1) const {
-        fp2 r = fp2_mul(fp2_select(role == 0, a0, a1), fp2_select(role == 0, b0, b1));
-        r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1);
+        const bool first = (role >> 1) == 0;
+        fp v = half_mul(fp2_select(first, a0, a1), fp2_select(first, b0, b1));
+        r0 = gather3(v, 0); r1 = gather3(v, 1);
     }
     __device__ __forceinline__ void fpmul6(fp (&r)[6], const fp (&a)[6], const fp (&b)[3]) const {
         fp xa = fp_select(role == 0, a[0], fp_select(role == 1, a[1], fp_select(role == 2, a[2], fp_select(role == 3, a[3], fp_select(role == 4, a[4], a[5])))));
@@ -336,26 +354,12 @@ struct team_lanes8 {
     }
 };
 __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return jac_dbl_team(p, team_lanes8{gbase, role}); }
-__device__ g2_jac g2_mul_x_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
-    g2_jac acc = jac_inf<fp2>();
-#pragma clang loop unroll(disable)
-    for (int i = 63; i >= 0; i--) {
-        acc = g2_dbl_coop(acc, gbase, role);
-        if ((k::X_ABS >> i) & 1) acc = jac_add(acc, p);
-    }
-    return jac_neg(acc);
-}
-// clear_cofactor_g2 (h2c.hpp) with the two 64-doubling chains lane-parallel
-__device__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
-    g2_jac t1 = g2_mul_x_coop(p, gbase, role);
-    g2_jac t2 = g2_psi(p);
-    g2_jac t3 = g2_psi(g2_psi(g2_dbl_coop(p, gbase, role)));
-    t3 = jac_add(t3, jac_neg(t2));
-    t2 = jac_add(t1, t2);
-    t2 = g2_mul_x_coop(t2, gbase, role);
-    t3 = jac_add(t3, t2);
-    t3 = jac_add(t3, jac_neg(t1));
-    return jac_add(t3, jac_neg(p));
+// clear_cofactor_g2 (h2c.hpp) with the two 63-doubling chains lane-parallel; the chain accumulator stays in registers (inlined
+// loop), the base point waits in the registers of the team (every lane holds it anyway)
+__device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
+    g2_park_regs park;
+    team_lanes8 team{gbase, role};
+    return clear_cofactor_g2_with(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); });
 }
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
@@ -1072,6 +1076,7 @@ struct team_wave_fp {               // every lane of the wave holds the same poi
         fp r = fp_sqr(fp_select(l == 0, a0, fp_select(l == 1, a1, a2)));
         r0 = fp_bcast(r, 0); r1 = fp_bcast(r, 1); r2 = fp_bcast(r, 2);
     }
+    __device__ __forceinline__ fp mul1(const fp& a, const fp& b) const { return fp_mul(a, b); }
 };
 __device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) { return jac_dbl_team(p, team_wave_fp{}); }
 __device__ __forceinline__ g1_jac dbl_coop(const g1_jac& p) { return g1_dbl_coop(p); }
