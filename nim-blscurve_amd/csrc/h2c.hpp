@@ -228,13 +228,13 @@ struct g2_park_regs {
 // accumulator a plain loop-carried value: inlined into the kernel it lives in registers for the whole chain (as the return
 // value of an out-of-line [x]-multiplication it lived in scratch memory and was stored back 84 words per doubling).
 // dbl: the doubling of the chain (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
-template <class Park, class Dbl>
-BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park, Dbl&& dbl) {
-    g2_jac base = p, u = p, res = p;
+template <class Pt, class Park, class Dbl>
+BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl) {
+    Pt base = p, u = p, res = p;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < 2; pass++) {
         park.put(base);
-        g2_jac acc = base;                                   // bit 63 of |x|
+        Pt acc = base;                                       // bit 63 of |x|
 #pragma clang loop unroll(disable)
         for (int i = 62; i >= 0; i--) {
             acc = dbl(acc);
@@ -242,7 +242,7 @@ BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park, Dbl&& dbl) {
         }
         acc = jac_neg(acc);                                  // x < 0
         if (pass == 0) {
-            g2_jac t2 = g2_psi(p);
+            Pt t2 = g2_psi(p);
             u = jac_add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));            // psi^2(2P) - psi(P)
             u = jac_add(u, jac_neg(acc));                                // - [x]P
             u = jac_add(u, jac_neg(p));                                  // - P

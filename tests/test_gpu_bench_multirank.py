@@ -12,13 +12,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("batch,port", [(4096, 29533), (65536, 29534)])
+def test_two_ranks_on_one_gpu(batch, port):
+    """batch = 65536: the per-GPU shard size of the headline configuration, every step's merged verdict asserted by the bench."""
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_ALL_ON_DEVICE0="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4096",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(batch),
            "--no-cpu", "--no-aux"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * batch and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_rccl_exchange_with_one_rank():
+    """The device-resident exchange of the N > 1 path (shard blob -> RCCL all_gather on device buffers -> merge + final
+    exponentiation, verdict read one step later) through a real RCCL communicator of one rank (an 8-GPU node is not available to
+    the tests): `bench.py --force-dist`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "4096", "--no-cpu", "--no-aux", "--force-dist"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"] == {"mode": "device"} and d["value"] > 0
