@@ -180,6 +180,24 @@ BLS_HD fp fp_neg(const fp& a) {
 
 BLS_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 
+// acc + a * b as ONE v_mad_i64_i32 whose addend IS the running accumulator.  Written as an asm statement on the device because
+// hipcc otherwise re-associates the column sum: it starts every column in a second register pair from 0 and joins the two with
+// an extra 64-bit add (v_lshl_add_u64) per column - 26 instructions of the ~490 of a product for instruction-level parallelism
+// that this stream does not need (a dependent chain of multiply-adds issues as fast as an independent one, tools/ubench_valu.hip).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_AB_NO_ASM_MAC)
+__device__ __forceinline__ int64_t bls_mac(int64_t acc, int32_t a, int32_t b) {
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    return acc;
+}
+__device__ __forceinline__ int64_t bls_mac_c(int64_t acc, int32_t a, uint32_t c) {      // c: a limb of p (scalar register)
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(c) : "vcc");
+    return acc;
+}
+#else
+BLS_HD int64_t bls_mac(int64_t acc, int32_t a, int32_t b) { return acc + (int64_t)a * b; }
+BLS_HD int64_t bls_mac_c(int64_t acc, int32_t a, uint32_t c) { return acc + (int64_t)a * (int32_t)c; }
+#endif
+
 // Montgomery product a*b*2^-392 mod p: product scanning, ONE signed 64-bit accumulator, 392 multiply-adds
 // (v_mad_i64_i32).  Operand limbs are at most limb-wise sums of two semi-normalised values (|l| < 2^29 + 16):
 // column bound 14 * (2^29.01)^2 + 14 * 2^56 + carry < 2^62.  m_k in [0, 2^28) makes the low 28
@@ -191,19 +209,19 @@ BLS_HD fp fp_mul_core(const fp& a, const fp& b) {
 #pragma unroll
     for (int kk = 0; kk < FP_N; kk++) {
 #pragma unroll
-        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+        for (int i = 0; i <= kk; i++) acc = bls_mac(acc, (int32_t)a.l[i], (int32_t)b.l[kk - i]);
 #pragma unroll
-        for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        for (int i = 0; i < kk; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
         m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
-        acc += (int64_t)m[kk] * (int32_t)k::P[0];
+        acc = bls_mac_c(acc, m[kk], k::P[0]);
         acc >>= 28;
     }
 #pragma unroll
     for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
 #pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac(acc, (int32_t)a.l[i], (int32_t)b.l[kk - i]);
 #pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
         r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
         acc >>= 28;
     }
@@ -224,16 +242,16 @@ BLS_HD fp fp_sqr_core(const fp& a) {
 #pragma unroll
     for (int kk = 0; kk < 2 * FP_N - 1; kk++) {
 #pragma unroll
-        for (int i = (kk < FP_N ? 0 : kk - FP_N + 1); 2 * i < kk; i++) acc += (int64_t)a2[i] * (int32_t)a.l[kk - i];
-        if ((kk & 1) == 0) acc += (int64_t)(int32_t)a.l[kk / 2] * (int32_t)a.l[kk / 2];
+        for (int i = (kk < FP_N ? 0 : kk - FP_N + 1); 2 * i < kk; i++) acc = bls_mac(acc, a2[i], (int32_t)a.l[kk - i]);
+        if ((kk & 1) == 0) acc = bls_mac(acc, (int32_t)a.l[kk / 2], (int32_t)a.l[kk / 2]);
         if (kk < FP_N) {
 #pragma unroll
-            for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+            for (int i = 0; i < kk; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
             m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
-            acc += (int64_t)m[kk] * (int32_t)k::P[0];
+            acc = bls_mac_c(acc, m[kk], k::P[0]);
         } else {
 #pragma unroll
-            for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+            for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
             r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
         }
         acc >>= 28;
@@ -255,23 +273,23 @@ BLS_HD fp fp_dot2_core(const fp& a, const fp& b, const fp& c, const fp& d) {
 #pragma unroll
     for (int kk = 0; kk < FP_N; kk++) {
 #pragma unroll
-        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+        for (int i = 0; i <= kk; i++) acc = bls_mac(acc, (int32_t)a.l[i], (int32_t)b.l[kk - i]);
 #pragma unroll
-        for (int i = 0; i <= kk; i++) acc += (int64_t)(int32_t)c.l[i] * (int32_t)d.l[kk - i];
+        for (int i = 0; i <= kk; i++) acc = bls_mac(acc, (int32_t)c.l[i], (int32_t)d.l[kk - i]);
 #pragma unroll
-        for (int i = 0; i < kk; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        for (int i = 0; i < kk; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
         m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
-        acc += (int64_t)m[kk] * (int32_t)k::P[0];
+        acc = bls_mac_c(acc, m[kk], k::P[0]);
         acc >>= 28;
     }
 #pragma unroll
     for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
 #pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[kk - i];
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac(acc, (int32_t)a.l[i], (int32_t)b.l[kk - i]);
 #pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)(int32_t)c.l[i] * (int32_t)d.l[kk - i];
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac(acc, (int32_t)c.l[i], (int32_t)d.l[kk - i]);
 #pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc += (int64_t)m[i] * (int32_t)k::P[kk - i];
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
         r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
         acc >>= 28;
     }
