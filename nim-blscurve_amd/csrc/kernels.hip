@@ -893,17 +893,17 @@ __device__ __forceinline__ int32_t pip_digit(const uint32_t (&kp)[9], uint32_t w
     return w + 1 == W.nwin ? raw : raw - (int32_t)(1u << (len - 1));
 }
 // lane per (point, window)
-__global__ void __launch_bounds__(WAVE) k_pip_hist(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t* __restrict__ hist) {
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
+__global__ void __launch_bounds__(WAVE) k_pip_hist(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t* __restrict__ hist) {
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = w0 + blockIdx.y;
     if (i >= n) return;
     uint32_t kp[9];
     pip_biased(kp, sc, i, W, sbytes);
     int32_t d = pip_digit(kp, w, W);
     if (d) atomicAdd(&hist[((size_t)w << W.cbk) + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
 }
-__global__ void __launch_bounds__(WAVE) k_pip_scatter(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(WAVE) k_pip_scatter(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t* __restrict__ cursor,
                                                       uint32_t* __restrict__ sorted) {
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = blockIdx.y;
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = w0 + blockIdx.y;
     if (i >= n) return;
     uint32_t kp[9];
     pip_biased(kp, sc, i, W, sbytes);
@@ -1005,10 +1005,11 @@ __global__ void __launch_bounds__(WAVE) k_pip_convert(const uint8_t* __restrict_
 template <class F>
 __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
                                                      const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t n, uint32_t cbk,
-                                                     uint32_t total, uint4* __restrict__ buckets) {
+                                                     uint32_t total, uint32_t g0, uint32_t gcount, uint4* __restrict__ buckets) {
+    // buckets g0 .. g0 + gcount - 1 (a group of windows); order[g0 + t] lists them by load, as indices relative to g0
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
-    if (t >= total) return;
-    uint32_t g = order ? order[t] : t;
+    if (t >= gcount) return;
+    uint32_t g = g0 + (order ? order[g0 + t] : t);
     uint32_t w = g >> cbk, cnt = hist[g], off = offs[g];
     const uint32_t* srt = sorted + (size_t)w * n + off;
     jac<F> acc = jac_inf<F>();
@@ -1023,9 +1024,10 @@ __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_b
 // lane per (window, segment of L buckets): sum_{j < L} (b0 + j + 1) * B_{b0 + j}
 template <class F>
 __global__ void __launch_bounds__(WAVE) k_pip_segred(const uint4* __restrict__ buckets, uint32_t total, uint32_t cbk, uint32_t L, uint32_t nseg_total,
-                                                     uint4* __restrict__ segout) {
+                                                     uint32_t t0, uint32_t tcount, uint4* __restrict__ segout) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
-    if (t >= nseg_total) return;
+    if (t >= tcount) return;
+    t += t0;
     uint32_t segs_per_win = (1u << cbk) / L;
     uint32_t w = t / segs_per_win, b0 = (t % segs_per_win) * L;
     jac<F> S = jac_inf<F>(), T = jac_inf<F>();
@@ -1045,8 +1047,8 @@ __global__ void __launch_bounds__(WAVE) k_pip_segred(const uint4* __restrict__ b
 }
 // grid (windows, nsplit): partial sums of a window's segment values
 template <class F>
-__global__ void __launch_bounds__(WAVE) k_pip_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t* __restrict__ part) {
-    uint32_t w = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
+__global__ void __launch_bounds__(WAVE) k_pip_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t w0, uint32_t* __restrict__ part) {
+    uint32_t w = w0 + blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
     jac<F> acc = jac_inf<F>();
     for (uint32_t j = sp * WAVE + threadIdx.x; j < segs_per_win; j += WAVE * nsplit)
         acc = padd(acc, soa_ld_jac(segout, nseg_total, (size_t)w * segs_per_win + j, (const jac<F>*)nullptr));
@@ -1087,8 +1089,8 @@ __device__ __forceinline__ g2_jac bcast0(const g2_jac& a) {
 }
 // one wave per window: R_w = sum of its nsplit partial sums, then 2^(off_w) * R_w
 template <class F>
-__global__ void __launch_bounds__(WAVE) k_pip_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, pip_win W, uint32_t* __restrict__ winout) {
-    uint32_t w = blockIdx.x;
+__global__ void __launch_bounds__(WAVE) k_pip_winsum(const uint32_t* __restrict__ part, uint32_t nsplit, pip_win W, uint32_t w0, uint32_t* __restrict__ winout) {
+    uint32_t w = w0 + blockIdx.x;
     jac<F> acc = jac_inf<F>();
     for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) acc = padd(acc, ld_jac_int(part + ((size_t)w * nsplit + j) * (3 * fld<F>::W), (const jac<F>*)nullptr));
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1345,13 +1347,17 @@ struct msm_ws {
     uint8_t* d_pts = nullptr;
     uint8_t* d_sc = nullptr;
     uint32_t* pts_int = nullptr;
-    uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr;
+    uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr, *part = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_bucketed = nullptr, ev_join = nullptr;
     uint4 *buckets = nullptr, *segout = nullptr;
 };
 static void msm_free(msm_ws* m) {
-    void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout};
+    void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout, m->part};
     for (void* x : b)
         if (x) (void)hipFree(x);
+    hipEvent_t ev[] = {m->ev_fork, m->ev_sorted, m->ev_bucketed, m->ev_join};
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
     *m = msm_ws();
 }
 
@@ -2208,13 +2214,18 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, const pip_win& W, size_t affb
     MALLOC(m->offs, (size_t)ct * 4);
     MALLOC(m->cursor, (size_t)ct * 4);
     MALLOC(m->order, (size_t)ct * 4);
-    MALLOC(m->chist, 256 * 4);
+    MALLOC(m->chist, 2 * 256 * 4);
+    MALLOC(m->part, 64 * 16 * G2W * 4);                 // per window up to 16 partial sums
     MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 52 + 1 windows (nbits 256 at 5-bit windows)
     MALLOC(m->buckets, (size_t)ct * 6 * 64);
     MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 6 * 64);
     MALLOC(m->winout, 64 * G2W * 4);
     MALLOC(m->out, 288);
 #undef MALLOC
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_bucketed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     m->cap_n = cb;
     m->cap_total = ct;
     return 0;
@@ -2240,26 +2251,67 @@ static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t 
     uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, segs_per_win = (1u << W.cbk) / MSM_SEG, nseg = nw * segs_per_win;
     const uint8_t* pts = (const uint8_t*)d_points;
     const uint8_t* sc = (const uint8_t*)d_scalars;
-    uint32_t nbp = (n + WAVE - 1) / WAVE, nbt = (total + WAVE - 1) / WAVE;
+    uint32_t nbp = (n + WAVE - 1) / WAVE;
+    uint32_t nsplit = segs_per_win >= 1024 ? 16 : (segs_per_win >= 128 ? 4 : 1);
+    // One group of windows = the whole pipeline on a range of windows [w0, w1): sort -> buckets -> segment sums -> window sums.
+    auto sort_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
+        uint32_t g0 = w0 << W.cbk, gc = (w1 - w0) << W.cbk, nbo = (gc + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
+        uint32_t* chist = m->chist + (w0 ? 256 : 0);
+        k_pip_hist<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->hist);
+        k_msm_scan<<<w1 - w0, WAVE, 0, s>>>(m->hist + g0, W.cbk, m->offs + g0, m->cursor + g0);
+        k_pip_scatter<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->cursor, m->sorted);
+        k_msm_order_hist<<<nbo, WAVE, 0, s>>>(m->hist + g0, gc, chist);
+        k_msm_order_scan<<<1, 1, 0, s>>>(chist);
+        k_msm_order_scatter<<<nbo, WAVE, 0, s>>>(m->hist + g0, gc, chist, m->order + g0);
+    };
+    auto bucket_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
+        uint32_t g0 = w0 << W.cbk, gc = (w1 - w0) << W.cbk;
+        k_pip_bucket<F><<<(gc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->pts_int, m->sorted, m->offs, m->hist, m->order, n, W.cbk, total, g0, gc, m->buckets);
+    };
+    auto reduce_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
+        uint32_t t0 = w0 * segs_per_win, tc = (w1 - w0) * segs_per_win;
+        k_pip_segred<F><<<(tc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, MSM_SEG, nseg, t0, tc, m->segout);
+        k_pip_winpart<F><<<dim3(w1 - w0, nsplit), WAVE, 0, s>>>(m->segout, nseg, segs_per_win, w0, m->part);
+        k_pip_winsum<F><<<w1 - w0, WAVE, 0, s>>>(m->part, nsplit, W, w0, m->winout);
+    };
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
-    HIPCHK(hipMemsetAsync(m->chist, 0, 256 * 4, st));
+    HIPCHK(hipMemsetAsync(m->chist, 0, 2 * 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_pip_convert<F><<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
-    k_pip_hist<<<dim3(nbp, nw), WAVE, 0, st>>>(sc, sbytes, n, W, m->hist);
-    k_msm_scan<<<nw, WAVE, 0, st>>>(m->hist, W.cbk, m->offs, m->cursor);
-    k_pip_scatter<<<dim3(nbp, nw), WAVE, 0, st>>>(sc, sbytes, n, W, m->cursor, m->sorted);
-    uint32_t nbo = (total + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
-    k_msm_order_hist<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist);
-    k_msm_order_scan<<<1, 1, 0, st>>>(m->chist);
-    k_msm_order_scatter<<<nbo, WAVE, 0, st>>>(m->hist, total, m->chist, m->order);
-    HIPCHK(hipEventRecord(c->ev[1], st));
-    k_pip_bucket<F><<<nbt, WAVE, 0, st>>>(m->pts_int, m->sorted, m->offs, m->hist, m->order, n, W.cbk, total, m->buckets);
-    HIPCHK(hipEventRecord(c->ev[2], st));
-    k_pip_segred<F><<<(nseg + WAVE - 1) / WAVE, WAVE, 0, st>>>(m->buckets, total, W.cbk, MSM_SEG, nseg, m->segout);
-    HIPCHK(hipEventRecord(c->ev[3], st));
-    uint32_t nsplit = segs_per_win >= 1024 ? 16 : (segs_per_win >= 128 ? 4 : 1);
-    k_pip_winpart<F><<<dim3(nw, nsplit), WAVE, 0, st>>>(m->segout, nseg, segs_per_win, reinterpret_cast<uint32_t*>(m->buckets));
-    k_pip_winsum<F><<<nw, WAVE, 0, st>>>(reinterpret_cast<const uint32_t*>(m->buckets), nsplit, W, m->winout);
+    // Two groups, software-pipelined over two streams: the HIGH windows first (their results need the long doubling chains:
+    // up to nbits - c dependent doublings on one wave per window, ~1 ms of pure latency), the LOW windows one stage behind on
+    // the context's side stream, so that the high group's serial tail runs beside the bucket accumulation of the low group and
+    // only the short chains of the low windows are left at the end (2^20 points: 7.2 -> 6.5 ms).  Large inputs only: a small
+    // MSM is latency-bound in every stage and gains nothing from the split.
+    const bool split = c->side && nw >= 4 && (size_t)n * nw >= ((size_t)1 << 22);
+    if (split) {
+        const uint32_t wh = nw / 2;                              // low group [0, wh), high group [wh, nw)
+        hipStream_t sd = c->side;
+        HIPCHK(hipEventRecord(m->ev_fork, st));                  // (the conversion of the points is behind this event)
+        sort_group(wh, nw, st);
+        HIPCHK(hipEventRecord(m->ev_sorted, st));
+        HIPCHK(hipEventRecord(c->ev[1], st));
+        bucket_group(wh, nw, st);
+        HIPCHK(hipEventRecord(m->ev_bucketed, st));
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        reduce_group(wh, nw, st);
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        HIPCHK(hipStreamWaitEvent(sd, m->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(sd, m->ev_sorted, 0));         // sort(low) beside bucket(high)
+        sort_group(0, wh, sd);
+        HIPCHK(hipStreamWaitEvent(sd, m->ev_bucketed, 0));       // bucket(low) beside the serial tail of the high group
+        bucket_group(0, wh, sd);
+        reduce_group(0, wh, sd);
+        HIPCHK(hipEventRecord(m->ev_join, sd));
+        HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+    } else {
+        sort_group(0, nw, st);
+        HIPCHK(hipEventRecord(c->ev[1], st));
+        bucket_group(0, nw, st);
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        reduce_group(0, nw, st);
+        HIPCHK(hipEventRecord(c->ev[3], st));
+    }
     k_pip_final<F><<<1, WAVE, 0, st>>>(m->winout, nw, m->out);
     HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(hipGetLastError());
