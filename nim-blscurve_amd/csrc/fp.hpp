@@ -184,7 +184,7 @@ BLS_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 // hipcc otherwise re-associates the column sum: it starts every column in a second register pair from 0 and joins the two with
 // an extra 64-bit add (v_lshl_add_u64) per column - 26 instructions of the ~490 of a product for instruction-level parallelism
 // that this stream does not need (a dependent chain of multiply-adds issues as fast as an independent one, tools/ubench_valu.hip).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_AB_NO_ASM_MAC)
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ int64_t bls_mac(int64_t acc, int32_t a, int32_t b) {
     asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
     return acc;
