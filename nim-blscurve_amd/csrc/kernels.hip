@@ -849,11 +849,19 @@ struct pip_win {
 __device__ __forceinline__ uint32_t pip_off(const pip_win& W, uint32_t w) {
     return w < W.wrem ? w * (W.wbase + 1) : W.wrem * (W.wbase + 1) + (w - W.wrem) * W.wbase;
 }
-// k' = (k mod 2^nbits) + H as 9 words; scalars little-endian, sbytes each
-__device__ __forceinline__ void pip_biased(uint32_t (&kp)[9], const uint8_t* __restrict__ sc, size_t i, const pip_win& W, uint32_t sbytes) {
+// Signed digit of window w of scalar i: k' = (k mod 2^nbits) + H (9 words; scalars little-endian, sbytes each), the len bits
+// of k' at the window's offset, minus the half (the top window is unbiased: 0 .. 2^(len-1), carry of the bias included).
+// The scalar is fetched with two 16-byte loads when it can be (blst_scalar arrays: sbytes = 32, 16-byte aligned) - one load
+// per word behind its own bounds test leaves a lane with eight dependent memory latencies; the two words of k' the window
+// needs are picked while the carry runs (w is uniform: no indexed register array).
+__device__ __forceinline__ int32_t pip_digit(const uint8_t* __restrict__ sc, size_t i, const pip_win& W, uint32_t sbytes, uint32_t w) {
     const uint8_t* p = sc + i * sbytes;
     uint32_t k[8];
-    if ((sbytes & 3) == 0 && (((uintptr_t)sc) & 3) == 0) {
+    if (sbytes == 32 && (((uintptr_t)sc) & 15) == 0) {
+        const uint4* pv = reinterpret_cast<const uint4*>(p);
+        uint4 a = pv[0], b = pv[1];
+        k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+    } else if ((sbytes & 3) == 0 && (((uintptr_t)sc) & 3) == 0) {
         const uint32_t* pw = reinterpret_cast<const uint32_t*>(p);
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = (uint32_t)(4 * j) < sbytes ? pw[j] : 0u;
@@ -866,51 +874,115 @@ __device__ __forceinline__ void pip_biased(uint32_t (&kp)[9], const uint8_t* __r
             k[j] = v;
         }
     }
-    uint32_t carry = 0;
+    const uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase, bit0 = pip_off(W, w), wi = bit0 >> 5, sh = bit0 & 31;
+    uint32_t carry = 0, lo = 0, hi = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        uint32_t lo = (uint32_t)(32 * j), v = k[j];
-        if (W.nbits <= lo) v = 0;
-        else if (W.nbits < lo + 32) v &= (1u << (W.nbits - lo)) - 1u;
+        uint32_t b0 = (uint32_t)(32 * j), v = k[j];
+        if (W.nbits <= b0) v = 0;
+        else if (W.nbits < b0 + 32) v &= (1u << (W.nbits - b0)) - 1u;
         uint64_t t = (uint64_t)v + W.H[j] + carry;
-        kp[j] = (uint32_t)t;
         carry = (uint32_t)(t >> 32);
+        if ((uint32_t)j == wi) lo = (uint32_t)t;
+        if ((uint32_t)j == wi + 1) hi = (uint32_t)t;
     }
-    kp[8] = W.H[8] + carry;
-}
-__device__ __forceinline__ uint32_t pip_bits(const uint32_t (&kp)[9], uint32_t bit0, uint32_t len) {     // len <= 31
-    uint32_t wi = bit0 >> 5, sh = bit0 & 31;
-    uint64_t v = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-        if ((uint32_t)j == wi) v = kp[j] | ((uint64_t)(j < 8 ? kp[j + 1 > 8 ? 8 : j + 1] : 0u) << 32);
-    return (uint32_t)(v >> sh) & ((1u << len) - 1u);
-}
-// signed digit of window w; the top window is unbiased (0 .. 2^(len-1), carry of the bias included)
-__device__ __forceinline__ int32_t pip_digit(const uint32_t (&kp)[9], uint32_t w, const pip_win& W) {
-    uint32_t len = w < W.wrem ? W.wbase + 1 : W.wbase;
-    int32_t raw = (int32_t)pip_bits(kp, pip_off(W, w), len);
+    uint32_t k8 = W.H[8] + carry;
+    if (wi == 8) lo = k8;
+    if (wi == 7) hi = k8;
+    int32_t raw = (int32_t)((uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & ((1u << len) - 1u));       // len <= 31
     return w + 1 == W.nwin ? raw : raw - (int32_t)(1u << (len - 1));
 }
 // lane per (point, window)
 __global__ void __launch_bounds__(WAVE) k_pip_hist(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t* __restrict__ hist) {
     uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = w0 + blockIdx.y;
     if (i >= n) return;
-    uint32_t kp[9];
-    pip_biased(kp, sc, i, W, sbytes);
-    int32_t d = pip_digit(kp, w, W);
+    int32_t d = pip_digit(sc, i, W, sbytes, w);
     if (d) atomicAdd(&hist[((size_t)w << W.cbk) + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
 }
 __global__ void __launch_bounds__(WAVE) k_pip_scatter(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t* __restrict__ cursor,
                                                       uint32_t* __restrict__ sorted) {
     uint32_t i = blockIdx.x * WAVE + threadIdx.x, w = w0 + blockIdx.y;
     if (i >= n) return;
-    uint32_t kp[9];
-    pip_biased(kp, sc, i, W, sbytes);
-    int32_t d = pip_digit(kp, w, W);
+    int32_t d = pip_digit(sc, i, W, sbytes, w);
     if (d) {
         uint32_t pos = atomicAdd(&cursor[((size_t)w << W.cbk) + (uint32_t)((d < 0 ? -d : d) - 1)], 1u);
         sorted[(size_t)w * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
+    }
+}
+
+// The same counting sort with the window's counters in LDS (2^cbk <= 32768 words = 128 KB of the CU's 160 KB): grid (slices,
+// windows), one 1024-thread workgroup per (slice of the points, window).  The global-atomic kernels above do one L2 atomic
+// per (point, window) - 16.8 M of them at 2^20 points, 1.7 ms for histogram + scatter; here the atomics are ds_add(_rtn)
+// and global memory sees each workgroup's counters once.
+//   k_pip_hist_lds     counts of one slice            -> shist[window][slice][bucket]
+//   k_pip_slice_scan   lane per bucket: exclusive prefix over the slices in place, total -> hist (then k_pip_scan_block -> offs)
+//   k_pip_scatter_lds  cursors = offs + slice prefix in LDS; position = ds_add_rtn
+constexpr uint32_t PIP_SORT_THREADS = 1024, PIP_SORT_MAX_CBK = 15, PIP_SLICES = 32;
+__global__ void __launch_bounds__(PIP_SORT_THREADS) k_pip_hist_lds(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t per,
+                                                                   uint32_t* __restrict__ shist) {
+    __shared__ uint32_t h[1u << PIP_SORT_MAX_CBK];
+    const uint32_t s = blockIdx.x, w = w0 + blockIdx.y, nb = 1u << W.cbk;
+    for (uint32_t b = threadIdx.x; b < nb; b += PIP_SORT_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint32_t lo = s * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PIP_SORT_THREADS) {
+        int32_t d = pip_digit(sc, i, W, sbytes, w);
+        if (d) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = shist + (((size_t)w * gridDim.x + s) << W.cbk);
+    for (uint32_t b = threadIdx.x; b < nb; b += PIP_SORT_THREADS) out[b] = h[b];
+}
+__global__ void __launch_bounds__(WAVE) k_pip_slice_scan(uint32_t* __restrict__ shist, uint32_t nslice, uint32_t cbk, uint32_t g0, uint32_t gcount,
+                                                         uint32_t* __restrict__ hist) {
+    uint32_t t = blockIdx.x * WAVE + threadIdx.x;
+    if (t >= gcount) return;
+    uint32_t g = g0 + t, w = g >> cbk, b = g & ((1u << cbk) - 1u), run = 0;
+    for (uint32_t s = 0; s < nslice; s++) {
+        uint32_t* p = shist + ((((size_t)w * nslice + s) << cbk) | b);
+        uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    hist[g] = run;
+}
+// exclusive scan of a window's bucket counts, one 1024-thread workgroup per window: thread t owns 2^cbk / 1024 consecutive buckets
+__global__ void __launch_bounds__(PIP_SORT_THREADS) k_pip_scan_block(const uint32_t* __restrict__ hist, uint32_t cbk, uint32_t* __restrict__ offs) {
+    __shared__ uint32_t wsum[PIP_SORT_THREADS / WAVE];
+    const uint32_t nb = 1u << cbk, per = nb / PIP_SORT_THREADS, t = threadIdx.x, lane = t & (WAVE - 1), wv = t / WAVE;
+    const uint32_t* h = hist + ((size_t)blockIdx.x << cbk) + (size_t)t * per;
+    uint32_t* o = offs + ((size_t)blockIdx.x << cbk) + (size_t)t * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) sum += h[j];
+    uint32_t incl = sum;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t v = __shfl_up(incl, d, WAVE);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == WAVE - 1) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t k = 0; k < wv; k++) run += wsum[k];
+    for (uint32_t j = 0; j < per; j++) {
+        o[j] = run;
+        run += h[j];
+    }
+}
+__global__ void __launch_bounds__(PIP_SORT_THREADS) k_pip_scatter_lds(const uint8_t* __restrict__ sc, uint32_t sbytes, uint32_t n, pip_win W, uint32_t w0, uint32_t per,
+                                                                      const uint32_t* __restrict__ shist, const uint32_t* __restrict__ offs,
+                                                                      uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t h[1u << PIP_SORT_MAX_CBK];
+    const uint32_t s = blockIdx.x, w = w0 + blockIdx.y, nb = 1u << W.cbk;
+    const uint32_t* pre = shist + (((size_t)w * gridDim.x + s) << W.cbk);
+    for (uint32_t b = threadIdx.x; b < nb; b += PIP_SORT_THREADS) h[b] = offs[((size_t)w << W.cbk) | b] + pre[b];
+    __syncthreads();
+    const uint32_t lo = s * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PIP_SORT_THREADS) {
+        int32_t d = pip_digit(sc, i, W, sbytes, w);
+        if (d) {
+            uint32_t pos = atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1)], 1u);
+            sorted[(size_t)w * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
+        }
     }
 }
 
@@ -1093,7 +1165,9 @@ __global__ void __launch_bounds__(WAVE) k_pip_winsum(const uint32_t* __restrict_
     uint32_t w = w0 + blockIdx.x;
     jac<F> acc = jac_inf<F>();
     for (uint32_t j = threadIdx.x; j < nsplit; j += WAVE) acc = padd(acc, ld_jac_int(part + ((size_t)w * nsplit + j) * (3 * fld<F>::W), (const jac<F>*)nullptr));
-    for (int d = 32; d >= 1; d >>= 1) {
+    int top = 32;
+    while (top >= 1 && (uint32_t)top >= nsplit) top >>= 1;          // lanes >= nsplit hold the neutral element
+    for (int d = top; d >= 1; d >>= 1) {
         jac<F> o = shfl_down_struct(acc, d);
         acc = padd(acc, o);
     }
@@ -1108,7 +1182,9 @@ template <class F>
 __global__ void __launch_bounds__(WAVE) k_pip_final(const uint32_t* __restrict__ winout, uint32_t nparts, uint32_t* __restrict__ out) {
     jac<F> acc = jac_inf<F>();
     for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = padd(acc, ld_jac_int(winout + (size_t)j * (3 * fld<F>::W), (const jac<F>*)nullptr));
-    for (int d = 32; d >= 1; d >>= 1) {
+    int top = 32;
+    while (top >= 1 && (uint32_t)top >= nparts) top >>= 1;
+    for (int d = top; d >= 1; d >>= 1) {
         jac<F> o = shfl_down_struct(acc, d);
         acc = padd(acc, o);
     }
@@ -1347,15 +1423,15 @@ struct msm_ws {
     uint8_t* d_pts = nullptr;
     uint8_t* d_sc = nullptr;
     uint32_t* pts_int = nullptr;
-    uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr, *part = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_bucketed = nullptr, ev_join = nullptr;
+    uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr, *part = nullptr, *shist = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_bucketed = nullptr, ev_join = nullptr;
     uint4 *buckets = nullptr, *segout = nullptr;
 };
 static void msm_free(msm_ws* m) {
-    void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout, m->part};
+    void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout, m->part, m->shist};
     for (void* x : b)
         if (x) (void)hipFree(x);
-    hipEvent_t ev[] = {m->ev_fork, m->ev_sorted, m->ev_bucketed, m->ev_join};
+    hipEvent_t ev[] = {m->ev_fork, m->ev_bucketed, m->ev_join};
     for (hipEvent_t e : ev)
         if (e) (void)hipEventDestroy(e);
     *m = msm_ws();
@@ -2214,16 +2290,16 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, const pip_win& W, size_t affb
     MALLOC(m->offs, (size_t)ct * 4);
     MALLOC(m->cursor, (size_t)ct * 4);
     MALLOC(m->order, (size_t)ct * 4);
-    MALLOC(m->chist, 2 * 256 * 4);
+    MALLOC(m->chist, 4 * 256 * 4);
+    MALLOC(m->shist, (size_t)ct * PIP_SLICES * 4);      // per-slice counters of the LDS counting sort
     MALLOC(m->part, 64 * 16 * G2W * 4);                 // per window up to 16 partial sums
     MALLOC(m->sorted, (size_t)cn * 64 * 4);          // up to 52 + 1 windows (nbits 256 at 5-bit windows)
     MALLOC(m->buckets, (size_t)ct * 6 * 64);
-    MALLOC(m->segout, (size_t)(ct / MSM_SEG + 64) * 6 * 64);
+    MALLOC(m->segout, (size_t)(ct / 4 + 64) * 6 * 64);
     MALLOC(m->winout, 64 * G2W * 4);
     MALLOC(m->out, 288);
 #undef MALLOC
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_bucketed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     m->cap_n = cb;
@@ -2248,18 +2324,31 @@ static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t 
     int rc = msm_reserve(c, npoints, W, AFFB);
     if (rc) return rc;
     msm_ws* m = c->msm;
-    uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, segs_per_win = (1u << W.cbk) / MSM_SEG, nseg = nw * segs_per_win;
+    uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, seg = W.cbk >= 12 ? 8u : MSM_SEG, segs_per_win = (1u << W.cbk) / seg,      // shorter running sums once they still fill the chip
+             nseg = nw * segs_per_win;
     const uint8_t* pts = (const uint8_t*)d_points;
     const uint8_t* sc = (const uint8_t*)d_scalars;
     uint32_t nbp = (n + WAVE - 1) / WAVE;
     uint32_t nsplit = segs_per_win >= 1024 ? 16 : (segs_per_win >= 128 ? 4 : 1);
     // One group of windows = the whole pipeline on a range of windows [w0, w1): sort -> buckets -> segment sums -> window sums.
-    auto sort_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
+    const bool lds_sort = W.cbk <= PIP_SORT_MAX_CBK && W.cbk >= 10 && n >= (1u << 15);        // counters of a window in LDS (large inputs)
+    auto count_sort = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
+        uint32_t g0 = w0 << W.cbk, gc = (w1 - w0) << W.cbk;
+        if (lds_sort) {
+            uint32_t per = (n + PIP_SLICES - 1) / PIP_SLICES;
+            k_pip_hist_lds<<<dim3(PIP_SLICES, w1 - w0), PIP_SORT_THREADS, 0, s>>>(sc, sbytes, n, W, w0, per, m->shist);
+            k_pip_slice_scan<<<(gc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->shist, PIP_SLICES, W.cbk, g0, gc, m->hist);
+            k_pip_scan_block<<<w1 - w0, PIP_SORT_THREADS, 0, s>>>(m->hist + g0, W.cbk, m->offs + g0);
+            k_pip_scatter_lds<<<dim3(PIP_SLICES, w1 - w0), PIP_SORT_THREADS, 0, s>>>(sc, sbytes, n, W, w0, per, m->shist, m->offs, m->sorted);
+        } else {
+            k_pip_hist<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->hist);
+            k_msm_scan<<<w1 - w0, WAVE, 0, s>>>(m->hist + g0, W.cbk, m->offs + g0, m->cursor + g0);
+            k_pip_scatter<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->cursor, m->sorted);
+        }
+    };
+    auto order_group = [&](uint32_t w0, uint32_t w1, uint32_t gi, hipStream_t s) {      // the group's buckets by load (indices relative to g0)
         uint32_t g0 = w0 << W.cbk, gc = (w1 - w0) << W.cbk, nbo = (gc + WAVE * MSM_ORD_PER - 1) / (WAVE * MSM_ORD_PER);
-        uint32_t* chist = m->chist + (w0 ? 256 : 0);
-        k_pip_hist<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->hist);
-        k_msm_scan<<<w1 - w0, WAVE, 0, s>>>(m->hist + g0, W.cbk, m->offs + g0, m->cursor + g0);
-        k_pip_scatter<<<dim3(nbp, w1 - w0), WAVE, 0, s>>>(sc, sbytes, n, W, w0, m->cursor, m->sorted);
+        uint32_t* chist = m->chist + 256 * gi;
         k_msm_order_hist<<<nbo, WAVE, 0, s>>>(m->hist + g0, gc, chist);
         k_msm_order_scan<<<1, 1, 0, s>>>(chist);
         k_msm_order_scatter<<<nbo, WAVE, 0, s>>>(m->hist + g0, gc, chist, m->order + g0);
@@ -2270,47 +2359,43 @@ static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t 
     };
     auto reduce_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
         uint32_t t0 = w0 * segs_per_win, tc = (w1 - w0) * segs_per_win;
-        k_pip_segred<F><<<(tc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, MSM_SEG, nseg, t0, tc, m->segout);
+        k_pip_segred<F><<<(tc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, seg, nseg, t0, tc, m->segout);
         k_pip_winpart<F><<<dim3(w1 - w0, nsplit), WAVE, 0, s>>>(m->segout, nseg, segs_per_win, w0, m->part);
         k_pip_winsum<F><<<w1 - w0, WAVE, 0, s>>>(m->part, nsplit, W, w0, m->winout);
     };
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
-    HIPCHK(hipMemsetAsync(m->chist, 0, 2 * 256 * 4, st));
+    HIPCHK(hipMemsetAsync(m->chist, 0, 4 * 256 * 4, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     k_pip_convert<F><<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
-    // Two groups, software-pipelined over two streams: the HIGH windows first (their results need the long doubling chains:
-    // up to nbits - c dependent doublings on one wave per window, ~1 ms of pure latency), the LOW windows one stage behind on
-    // the context's side stream, so that the high group's serial tail runs beside the bucket accumulation of the low group and
-    // only the short chains of the low windows are left at the end (2^20 points: 7.2 -> 6.5 ms).  Large inputs only: a small
-    // MSM is latency-bound in every stage and gains nothing from the split.
+    // The counting sort covers all windows; then two groups of windows, each on its own stream: the HIGH windows first (their
+    // results need the long doubling chains: up to nbits - c dependent doublings on one wave per window, ~1 ms of pure
+    // latency), the LOW windows' bucket kernel behind the high one, so that the high group's serial tail runs beside the bucket
+    // accumulation of the low group and only the short chains of the low windows are left at the end.  More groups lose more
+    // in the bucket kernels' tails than they hide.  Large inputs only: a small MSM is latency-bound in every stage.
     const bool split = c->side && nw >= 4 && (size_t)n * nw >= ((size_t)1 << 22);
+    uint32_t cut[3] = {nw, 0, 0}, ngroups = 1;                      // groups [cut[g + 1], cut[g]), from the high windows down
     if (split) {
-        const uint32_t wh = nw / 2;                              // low group [0, wh), high group [wh, nw)
-        hipStream_t sd = c->side;
-        HIPCHK(hipEventRecord(m->ev_fork, st));                  // (the conversion of the points is behind this event)
-        sort_group(wh, nw, st);
-        HIPCHK(hipEventRecord(m->ev_sorted, st));
-        HIPCHK(hipEventRecord(c->ev[1], st));
-        bucket_group(wh, nw, st);
-        HIPCHK(hipEventRecord(m->ev_bucketed, st));
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        reduce_group(wh, nw, st);
-        HIPCHK(hipEventRecord(c->ev[3], st));
-        HIPCHK(hipStreamWaitEvent(sd, m->ev_fork, 0));
-        HIPCHK(hipStreamWaitEvent(sd, m->ev_sorted, 0));         // sort(low) beside bucket(high)
-        sort_group(0, wh, sd);
-        HIPCHK(hipStreamWaitEvent(sd, m->ev_bucketed, 0));       // bucket(low) beside the serial tail of the high group
-        bucket_group(0, wh, sd);
-        reduce_group(0, wh, sd);
-        HIPCHK(hipEventRecord(m->ev_join, sd));
-        HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
-    } else {
-        sort_group(0, nw, st);
-        HIPCHK(hipEventRecord(c->ev[1], st));
-        bucket_group(0, nw, st);
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        reduce_group(0, nw, st);
-        HIPCHK(hipEventRecord(c->ev[3], st));
+        cut[1] = nw / 2;
+        ngroups = 2;
+    }
+    // group g runs on its own stream, its bucket kernel behind the bucket kernel of group g - 1: the (latency-bound, few-wave)
+    // reduction of a group is dispatched before the next group's bucket kernel and runs beside it
+    hipStream_t gs[2] = {st, c->side};
+    hipEvent_t gev[2] = {m->ev_fork, m->ev_bucketed};
+    count_sort(0, nw, st);
+    for (uint32_t g = 0; g < ngroups; g++) order_group(cut[g + 1], cut[g], g, st);
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    for (uint32_t g = 0; g < ngroups; g++) {
+        if (g) HIPCHK(hipStreamWaitEvent(gs[g], gev[g - 1], 0));
+        bucket_group(cut[g + 1], cut[g], gs[g]);
+        HIPCHK(hipEventRecord(gev[g], gs[g]));
+        if (g == 0) HIPCHK(hipEventRecord(c->ev[2], st));
+        reduce_group(cut[g + 1], cut[g], gs[g]);
+        if (g == 0) HIPCHK(hipEventRecord(c->ev[3], st));
+    }
+    for (uint32_t g = 1; g < ngroups; g++) {
+        HIPCHK(hipEventRecord(gev[g], gs[g]));
+        HIPCHK(hipStreamWaitEvent(st, gev[g], 0));
     }
     k_pip_final<F><<<1, WAVE, 0, st>>>(m->winout, nw, m->out);
     HIPCHK(hipEventRecord(c->ev[4], st));

@@ -50,7 +50,7 @@ def test_msm_edges(m, cache):
     assert g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts[:96] + neg, sc[:32] * 2, 255)) is None
 
 
-@pytest.mark.parametrize("n", [1000, 20000])
+@pytest.mark.parametrize("n", [1000, 20000, 50000])
 def test_msm_vs_c_oracle(m, cache, n):
     """bench shape: P_i = [a_i]G with 96-bit a_i, 32 random scalar bytes, nbits = 255."""
     import c_oracle as co
@@ -62,6 +62,25 @@ def test_msm_vs_c_oracle(m, cache, n):
     print("msm", n, "timings(ms):", cache.timings())
     assert o.g1_to_blst_affine(g1_jac_to_affine(out)) == co.msm_g1(pts, sc, 255)
     assert cache.timings()["total"] < 40.0          # full-width random scalars must not pile up in one bucket (top-window carry)
+
+
+@pytest.mark.parametrize("n,nbits", [(40000, 255), (33000, 64), (70001, 130)])
+def test_msm_lds_sort_path(m, cache, n, nbits):
+    """n >= 2^15: the counting sort with a window's counters in LDS (k_pip_hist_lds / k_pip_scatter_lds) and the two window
+    groups; 32-byte scalar images (two 16-byte loads), blst's own (nbits + 7) / 8 spacing (8: word loads, 17: byte loads), a
+    ragged last slice, the exact blst argument list."""
+    import c_oracle as co
+    rng = random.Random(n)
+    base = [co.sk_to_pk(rng.getrandbits(96) | 1) for _ in range(1500)]
+    pts = b"".join(base[i % len(base)] for i in range(n))
+    sb = (nbits + 7) // 8
+    ks = [rng.getrandbits(nbits) for _ in range(n)]
+    want = co.msm_g1(pts, b"".join(k.to_bytes(32, "little") for k in ks), nbits)
+    got = m.blst_p1s_mult_pippenger(pts, b"".join(k.to_bytes(sb, "little") for k in ks), nbits)
+    assert o.g1_to_blst_affine(g1_jac_to_affine(got)) == want
+    if nbits == 255:
+        got = m.p1s_mult_pippenger(cache, pts, b"".join(k.to_bytes(32, "little") for k in ks), nbits)
+        assert o.g1_to_blst_affine(g1_jac_to_affine(got)) == want
 
 
 def test_msm_linearity_at_2_20(m, cache):
