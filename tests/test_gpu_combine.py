@@ -108,3 +108,22 @@ def test_g2_pippenger_entry_points(m):
     got = m.p2s_mult_pippenger_device(cache, dp.data_ptr(), n, ds.data_ptr(), 255)
     assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == co.msm_g2(pts, sc, 255, 32)
     m.lib().mi355_bls_default_ctx_release()
+
+
+def test_g2_pippenger_lds_sort_path(m):
+    """G2 MSM at n >= 2^15 (the counting sort with the counters in LDS, shared with G1): 64-bit scalars as `combine` passes them
+    (core :639-646) and 255-bit ones, against the C restatement."""
+    import random
+    import c_oracle as co
+    from util import g2_jac_to_affine
+    rng = random.Random(5)
+    h = co.hash_to_g2(b"g2 msm big", o.DST_SIG)
+    base = [co.g2_mul(h, rng.randrange(1, o.R)) for _ in range(64)]
+    for n, nbits in ((33000, 64), (40000, 255)):
+        pts = b"".join(base[i % 64] for i in range(n))
+        sb = (nbits + 7) // 8
+        sc = bytes(rng.getrandbits(8) for _ in range(sb * n))
+        if nbits == 255:
+            sc = b"".join(sc[32 * i:32 * i + 31] + bytes([sc[32 * i + 31] & 0x7f]) for i in range(n))
+        got = m.blst_p2s_mult_pippenger(pts, sc, nbits)
+        assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == co.msm_g2(pts, sc, nbits, sb), (n, nbits)
