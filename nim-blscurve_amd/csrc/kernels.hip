@@ -540,8 +540,9 @@ struct c12_lds {
     uint32_t steps[N_LINES * 6 * 2 * FP_N];     // the 68 step products, flat basis (46 KB): loaded once, no global load per Horner step
 };
 
-// d = a * b (flat basis); d may be a or b
-__device__ __noinline__ void c12_mul(c12_lds& S, int d, int a, int b) {
+// d = a * b (flat basis); d may be a or b.  LDS: any block-shared struct with the registers r[][6] and the work area w.
+template <class LDS>
+__device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
     int lane = threadIdx.x;
     if (lane < 108) S.w.prod[lane] = c12_phase1(S.r[a], S.r[b], lane, false);
     __syncthreads();
@@ -618,6 +619,48 @@ __device__ __forceinline__ void c12_set_one(c12_lds& S, int d) {
     if (lane < 6) S.r[d][lane] = lane == 0 ? fp2_one() : fp2_zero();
     __syncthreads();
 }
+// internal Fp12 layout (tower order, FPW words per Fp) <-> engine register
+template <class LDS>
+__device__ __forceinline__ void c12_load_int(LDS& S, int d, const uint32_t* g) {
+    int lane = threadIdx.x;
+    if (lane < 12) {
+        fp v = ld_fp_int(g + lane * FPW);
+        fp2& dst = S.r[d][c12_flat_of_tower(lane >> 1)];
+        if (lane & 1) dst.c1 = v; else dst.c0 = v;
+    }
+    __syncthreads();
+}
+template <class LDS>
+__device__ __forceinline__ void c12_store_int(const LDS& S, int a, uint32_t* g) {
+    int lane = threadIdx.x;
+    if (lane < 12) {
+        const fp2& v = S.r[a][c12_flat_of_tower(lane >> 1)];
+        st_fp_int(g + lane * FPW, (lane & 1) ? v.c1 : v.c0);
+    }
+    __syncthreads();
+}
+// Latency mode: the per-lane partial products of k_lineprod folded on the engine.  grid (N_LINES, nb): block (s, b) multiplies
+// `per` consecutive partials of step s (the last block: last_count) -> dst[s * nb + b]; two levels of about sqrt(count)
+// dependent engine products (~4.5 us each) where the in-wave shuffle tree (6 whole Fp12 multiplications per lane) plus a
+// per-lane fold took ~0.8 ms.
+struct fold_lds {
+    fp2 r[2][6];
+    c12_work w;
+};
+__global__ void __launch_bounds__(TAIL_THREADS) k_fold(const uint32_t* __restrict__ src, uint32_t count, uint32_t per, uint32_t last_count,
+                                                       uint32_t* __restrict__ dst) {
+    __shared__ fold_lds S;
+    const uint32_t s = blockIdx.x, b = blockIdx.y, nb = gridDim.y;
+    const uint32_t lo = b * per, cnt = b + 1 == nb ? last_count : per;
+    const uint32_t* g = src + ((size_t)s * count + lo) * F12W;
+    c12_load_int(S, 0, g);
+    for (uint32_t j = 1; j < cnt; j++) {
+        c12_load_int(S, 1, g + (size_t)j * F12W);
+        c12_mul(S, 0, 0, 1);
+    }
+    c12_store_int(S, 0, dst + ((size_t)s * nb + b) * F12W);
+}
+
 // d = a^x (x < 0, a cyclotomic): square-and-multiply over |x|, then conjugate.  tmp != a.
 __device__ __noinline__ void c12_cyc_exp_x(c12_lds& S, int d, int a, int tmp) {
     c12_copy(S, tmp, a);
@@ -1563,7 +1606,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_msg, 4096 + 192);
     ALLOC(c->d_comp, max_sets * 320);          // wire-format staging: keys (<= 96 B) | messages (32 B) | signatures (<= 192 B)
     ALLOC(c->d_status, max_sets);
-    ALLOC(c->d_lpart, (size_t)N_LINES * c->nblk_cap * WAVE * F12W * 4);     // per-lane partial products of k_lineprod
+    ALLOC(c->d_lpart, (size_t)N_LINES * (c->nblk_cap * (WAVE + 1) + 64) * F12W * 4);     // per-lane partial products of k_lineprod (+ k_fold's first-level results)
     ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
@@ -1770,13 +1813,23 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
     if (m < 1) m = 1;
     nblk = (npairs + WAVE * m - 1) / (WAVE * m);
-    // throughput mode: every lane hands its partial product to k_lineprod2 (68 waves fold 64 x nblk partials per step: least
-    // total work); latency mode: the in-wave product tree runs in k_lineprod's waves (+6 Fp12 products per wave) and
-    // k_lineprod2 only folds nblk partials per step (one caller, 65 536 tuples: 1.8 -> 0.4 ms)
-    int per_lane = c->coop ? 0 : 1;
-    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, per_lane);
+    // every lane hands its partial product over (64 x nblk per step).  Throughput mode: k_lineprod2's 68 waves fold them,
+    // 15 sequential Fp12 products per lane + one shuffle tree (least total work); latency mode: k_fold on the lane-cooperative
+    // engine, 64 per block and then the nblk block results (one caller, 65 536 tuples: 1.8 -> 0.35 ms)
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, 1);
     HIPCHK(hipEventRecord(c->ev_lp, st));
-    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, per_lane ? nblk * WAVE : nblk, c->d_L);
+    if (c->coop) {
+        size_t first_last = (size_t)(nblk - 1) * WAVE * m;             // lanes past the last pair hold 1: not folded
+        uint32_t live = (nblk - 1) * WAVE + (npairs - first_last < WAVE ? (uint32_t)(npairs - first_last) : WAVE);
+        uint32_t per = 1;                                              // two levels of about sqrt(live) dependent products each
+        while (per * per < live) per++;
+        uint32_t nb1 = (live + per - 1) / per;
+        uint32_t* mid = c->d_lpart + (size_t)N_LINES * c->nblk_cap * WAVE * F12W;
+        k_fold<<<dim3(N_LINES, nb1), TAIL_THREADS, 0, st>>>(c->d_lpart, nblk * WAVE, per, live - (nb1 - 1) * per, nb1 > 1 ? mid : c->d_L);
+        if (nb1 > 1) k_fold<<<dim3(N_LINES, 1), TAIL_THREADS, 0, st>>>(mid, nb1, nb1, nb1, c->d_L);
+    } else {
+        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk * WAVE, c->d_L);
+    }
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
     k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
