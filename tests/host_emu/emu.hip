@@ -13,6 +13,7 @@ void emu_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r,
 void emu_fp_add(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_add(fp_load_le(a), fp_load_le(b))); }
 void emu_fp_sub(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp_store_le(r, fp_sub(fp_load_le(a), fp_load_le(b))); }
 void emu_fp_inv(const uint8_t* a, uint8_t* r) { fp_store_le(r, fp_inv(fp_load_le(a))); }
+void emu_fp_inv_fermat(const uint8_t* a, uint8_t* r) { fp_store_le(r, fp_inv_fermat(fp_load_le(a))); }
 void emu_fp2_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { fp2_store_le(r, fp2_mul(fp2_load_le(a), fp2_load_le(b))); }
 void emu_fp2_sqr(const uint8_t* a, uint8_t* r) { fp2_store_le(r, fp2_sqr(fp2_load_le(a))); }
 void emu_fp2_inv(const uint8_t* a, uint8_t* r) { fp2_store_le(r, fp2_inv(fp2_load_le(a))); }

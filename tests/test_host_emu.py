@@ -31,6 +31,22 @@ def test_fields(emu):
         assert call(emu, "emu_fp2_inv", A, outlen=96).hex() == "".join(i)
 
 
+def test_inversion_by_division_steps_equals_fermat(emu):
+    """fp_inv (Bernstein-Yang division steps, 62 per batch) against the exponentiation a^(p-2) it replaced, and a * 1/a = 1:
+    random values, the edge values 0, 1, 2, p - 1, p - 2 and small / sparse ones (few batches, early exit)."""
+    rng = random.Random(11)
+    vals = [0, 1, 2, o.P - 1, o.P - 2, (o.P + 1) // 2, 1 << 380, (1 << 62) - 1, 1 << 62, (1 << 124) + 1]
+    vals += [rng.randrange(o.P) for _ in range(300)] + [rng.getrandbits(b) for b in (1, 7, 33, 63, 64, 65, 190, 379)]
+    two = (2).to_bytes(48, "little")
+    one = call(emu, "emu_fp_mul", two, call(emu, "emu_fp_inv_fermat", two))          # the image of 1 in the byte format of the harness
+    for v in vals:
+        a = (v % o.P).to_bytes(48, "little")
+        got = call(emu, "emu_fp_inv", a)
+        assert got == call(emu, "emu_fp_inv_fermat", a), hex(v)
+        if v % o.P:
+            assert call(emu, "emu_fp_mul", a, got) == one
+
+
 def test_sha256(emu):
     rng = random.Random(1)
     for n in [0, 1, 31, 32, 55, 56, 63, 64, 65, 119, 120, 128, 200]:

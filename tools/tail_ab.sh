@@ -1,0 +1,19 @@
+# k_tail / k_fold average durations (rocprofv3 --kernel-trace --stats of tests/gpu_probe_lat.py) for prebuilt variants/<name>.so
+R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so
+for v in "$@"; do
+  cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+  rm -rf /tmp/kt_$v
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$v -o t -- python3 $R/tests/gpu_probe_lat.py > /dev/null 2>&1
+  python3 - <<PY
+import csv,glob
+f=glob.glob("/tmp/kt_$v/**/t_kernel_stats.csv",recursive=True)[0]
+out=[]
+for r in csv.DictReader(open(f)):
+    n=r["Name"]
+    for k in ("k_tail","k_fold","k_lineprod2"):
+        if k+"(" in n: out.append("%s calls %s avg %.3f min %.3f" % (k, r["Calls"], float(r["AverageNs"])/1e6, float(r["MinNs"])/1e6))
+print("$v:", "; ".join(out))
+PY
+done
+cp /tmp/keep.so $R/nim-blscurve_amd/libblscurve_mi355x.so
