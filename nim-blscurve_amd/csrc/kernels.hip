@@ -531,10 +531,11 @@ __global__ void __launch_bounds__(WAVE) k_lineprod2(const uint32_t* __restrict__
 // i.e. ~1.3 Fp2-mul latencies instead of 18 on a single lane.
 // ------------------------------------------------------------------------------------------
 constexpr int C12_NREG = 8;
-#ifndef BLS_TAIL_THREADS
-#define BLS_TAIL_THREADS 192
-#endif
-constexpr int TAIL_THREADS = BLS_TAIL_THREADS;     // three waves: the 108 products of an Fp12 multiplication and the 168 items of its second phase in ONE round each (128 threads: 8 % slower)
+// Threads of the engine's workgroup (the kernels read blockDim.x).  Three waves run the 108 products of an Fp12 multiplication
+// and the 168 items of its second phase in ONE round each: the latency-mode launch (two waves: 8 % slower).  Throughput mode
+// launches two waves: with the chip saturated by 512-register waves a workgroup waits until enough SIMDs of ONE CU have
+// drained, at the head of a hardware queue that other callers' streams share (three waves: +3.6 % per pipelined batch).
+constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 128;          // both >= 108: phase 1 is one product per thread
 struct c12_lds {
     fp2 r[C12_NREG][6];
     c12_work w;
@@ -549,7 +550,7 @@ __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
     int lane = threadIdx.x;
     if (lane < 108) S.w.prod[lane] = c12_phase1(S.r[a], S.r[b], lane, false);
     __syncthreads();
-    for (int t = lane; t < 12 * FP_N; t += TAIL_THREADS) c12_phase2a(S.w, t, false);
+    for (int t = lane; t < 12 * FP_N; t += (int)blockDim.x) c12_phase2a(S.w, t, false);
     __syncthreads();
     if (lane < 12) {
         fp v = c12_phase2b(S.w, lane);
@@ -562,7 +563,7 @@ __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
     int lane = threadIdx.x;
     if (lane < 63) S.w.prod[lane] = c12_phase1(S.r[a], S.r[a], lane, true);
     __syncthreads();
-    for (int t = lane; t < 12 * FP_N; t += TAIL_THREADS) c12_phase2a(S.w, t, true);
+    for (int t = lane; t < 12 * FP_N; t += (int)blockDim.x) c12_phase2a(S.w, t, true);
     __syncthreads();
     if (lane < 12) {
         fp v = c12_phase2b(S.w, lane);
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
     }
     if (mode & 1) {
         // all 68 step products into LDS, dropping the two pad words of every Fp
-        for (int e = lane; e < N_LINES * 12 * FP_N; e += TAIL_THREADS) S.steps[e] = L[(size_t)(e / FP_N) * FPW + (e % FP_N)];
+        for (int e = lane; e < N_LINES * 12 * FP_N; e += (int)blockDim.x) S.steps[e] = L[(size_t)(e / FP_N) * FPW + (e % FP_N)];
     }
     __syncthreads();
     enum { F = 0, T = 1, A = 2, B = 3, C = 4, X1 = 5, X2 = 6, X3 = 7 };
@@ -1730,6 +1731,7 @@ static void host_combine_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
 // (coop): the tuple pairs fill the chip exactly, so the few extra pairs would be a second round of waves that takes as long as
 // the first (2.2 ms at 3 % occupancy); with 8 lanes per pair they take ~1 ms instead.  In throughput mode (several batches
 // in flight) that second round overlaps other batches' kernels and one lane per pair is the cheaper form.
+static inline int tail_threads(const mi355_bls_ctx* c) { return c->coop ? TAIL_THREADS : TAIL_THREADS_TP; }
 static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipStream_t st) {
     if (c->coop && (npairs + 7) / 8 <= c->slots) {
         k_lines_coop<<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
@@ -1835,7 +1837,7 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     }
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
-    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 1, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[7], st));
     HIPCHK(hipGetLastError());
     c->last_n = n;
@@ -1871,7 +1873,7 @@ static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, con
     uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
     int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
     if (rc) return rc;
-    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[8], st));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 8, hipMemcpyDeviceToHost, st));
     c->pending = true;
@@ -2012,7 +2014,7 @@ extern "C" int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* c, const
     }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
                                (uint32_t)(stride_bytes / 4), 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_flags + 3, c->d_flags + 3, 4, hipMemcpyDeviceToHost, st));
