@@ -1770,8 +1770,13 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
     const bool fork = c->coop && c->side && n32 <= 16 * c->slots;       // pk + signature side beside the hashing
-    hipStream_t sd = fork ? c->side : st;
-    if (fork) HIPCHK(hipStreamWaitEvent(sd, c->ev[1], 0));
+    // A whole-chip batch of ONE caller (latency mode): the signature side and the Miller lines of its extra pairs run on the side
+    // stream beside the hashing.  The tuple pairs then fill the chip's wave slots exactly once; behind them the extra pairs
+    // would be a second round of waves (or ~1 ms of the 8-lanes-per-pair kernel).
+    const bool fork_sig = !fork && c->coop && c->side;
+    hipStream_t sd = fork ? c->side : st;                               // [r]PK
+    hipStream_t ss = (fork || fork_sig) ? c->side : st;                 // signature side
+    if (fork || fork_sig) HIPCHK(hipStreamWaitEvent(c->side, c->ev[1], 0));
     // ---- hashing (caller's stream)
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
@@ -1790,27 +1795,34 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     {
         msm_win W{nwin, cw, 0};
         uint32_t *hist = c->d_sig_hist, *offs = hist + SIG_SLOTS_MAX, *cursor = offs + SIG_SLOTS_MAX;
-        HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, sd));
-        k_sig_convert<<<nb, WAVE, 0, sd>>>(d_sets, n32, c->d_sig_pts);
-        k_msm_hist<<<dim3(nb, nwin), WAVE, 0, sd>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
-        k_msm_scan<<<nwin, WAVE, 0, sd>>>(hist, cw, offs, cursor);
-        k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, sd>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
+        HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, ss));
+        k_sig_convert<<<nb, WAVE, 0, ss>>>(d_sets, n32, c->d_sig_pts);
+        k_msm_hist<<<dim3(nb, nwin), WAVE, 0, ss>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
+        k_msm_scan<<<nwin, WAVE, 0, ss>>>(hist, cw, offs, cursor);
+        k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, ss>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
         uint32_t per = n32 >> cw, lshift = 0;                          // expected entries per bucket; ~16 per lane
         while (lshift < 6 && (per >> (lshift + 1)) >= 16) lshift++;
         // small batches leave most of the chip idle: more lanes per bucket (down to ~2 entries per lane) shorten the kernel
         while (lshift < 6 && ((total << (lshift + 1)) <= 16 * c->slots) && (per >> (lshift + 1)) >= 2) lshift++;
-        k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, sd>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
+        k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, ss>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
                                                                              c->d_sig_consts + (cw == 8 ? (size_t)SIG_SLOTS_MAX * G1W : 0), c->d_H, c->d_P,
                                                                              c->stride);
         c->sig_c = cw;
         c->sig_slots = total;
         c->agg_valid = false;
     }
-    HIPCHK(hipEventRecord(c->ev[4], sd));
-    if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));              // join
     // ---- Miller lines and their products per step
     uint32_t npairs = n32 + total;
-    launch_lines(c, npairs, total, st);
+    if (fork_sig) {
+        k_lines<<<(total + WAVE - 1) / WAVE, WAVE, 0, ss>>>(c->d_P, c->d_H, n32, total, c->stride, c->d_lines);
+        HIPCHK(hipEventRecord(c->ev[4], ss));
+        launch_lines(c, n32, 0, st);
+        HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));                    // join
+    } else {
+        HIPCHK(hipEventRecord(c->ev[4], ss));
+        if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));          // join
+        launch_lines(c, npairs, total, st);
+    }
     HIPCHK(hipEventRecord(c->ev[5], st));
     uint32_t nblk = c->slots / N_LINES;
     if (nblk < 1) nblk = 1;
