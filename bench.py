@@ -272,7 +272,12 @@ def main():
             one = {"kernel_alone_ms": {**timed_kernel_ms, "k_sig_bucket": stage_ms.get("sig_mul_sum", 0.0)}, "tail_ms_alone": {}, "value_one_caller": None,
                    "ms_one_caller": None}
         else:
-            one = one_caller_rows(m, cache, streams[0], d_sets, n, n_total, lo, hi, rnd, sharded_path)
+            if throughput_mode:
+                cache_tp = caches[0]
+            else:
+                cache_tp = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)
+                cache_tp.set_cooperative(False)
+            one = one_caller_rows(m, cache, cache_tp, streams[0], d_sets, n, n_total, lo, hi, rnd, sharded_path)
         alone = one["kernel_alone_ms"]
         dom = max(alone, key=lambda k: alone[k])                   # the dominant single kernel, by its un-overlapped duration
         alg_bytes = KERNEL_BYTES[dom] * n
@@ -302,6 +307,7 @@ def main():
                        "exchange": exchange if sharded_path else None},
             "value_one_caller": one["value_one_caller"],
             "ms_one_caller": one["ms_one_caller"],
+            "stage_ms_one_caller": one.get("stage_ms_one_caller"),
             "value_host_buffers": one.get("value_host_buffers"),
             "ms_host_buffers": one.get("ms_host_buffers"),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -324,7 +330,9 @@ def main():
             "kernel_ms_alone": {k: round(v, 3) for k, v in alone.items()},
             "tail_ms_alone": {k: round(v, 3) for k, v in one["tail_ms_alone"].items()},
             "stage_ms_note": "stage_ms / kernel_ms_timed_region: HIP-event durations inside the timed region (with %d batches in flight they include "
-                             "time shared with other batches' kernels); kernel_ms_alone: one un-overlapped caller after the timed region" % inflight,
+                             "time shared with other batches' kernels); kernel_ms_alone / tail_ms_alone: ONE blocking caller of a throughput-mode context after the "
+                             "timed region (every kernel alone on the chip); ms_one_caller / stage_ms_one_caller: one blocking caller of a latency-mode "
+                             "context (fork streams: its stages overlap)" % inflight,
             "input_gen_s": round(gen_s, 1),
         }
         if not a.no_aux and world == 1 and not a.force_dist:
@@ -339,23 +347,33 @@ def main():
         dist.destroy_process_group()
 
 
-def one_caller_rows(m, cache, stream, d_sets, n, n_total, lo, hi, rnd, sharded_path):
-    """ONE blocking caller after the timed region: kernel-alone durations (nothing else on the chip), the single-caller
-    rate ('kernels-only' with inputs resident) and the PCIe-inclusive rate of the host-buffer entry point."""
+def one_caller_rows(m, cache, cache_tp, stream, d_sets, n, n_total, lo, hi, rnd, sharded_path):
+    """ONE blocking caller after the timed region: the single-caller rate ('kernels-only' with inputs resident) on
+    the latency-mode context `cache`; kernel-alone durations from ONE blocking caller of a throughput-mode context `cache_tp`
+    (one lane per item, no fork stream: every kernel has the chip to itself between its two events); the PCIe-inclusive rate
+    of the host-buffer entry point."""
     out = {}
     reps = 5
-    call = (lambda: cache.verify_device(d_sets.data_ptr(), n, rnd, stream.cuda_stream)) if not sharded_path else \
-           (lambda: cache.shard_device(d_sets.data_ptr(), n_total, lo, hi, rnd, stream.cuda_stream)[1])
+
+    def caller(c):
+        return (lambda: c.verify_device(d_sets.data_ptr(), n, rnd, stream.cuda_stream)) if not sharded_path else \
+               (lambda: c.shard_device(d_sets.data_ptr(), n_total, lo, hi, rnd, stream.cuda_stream)[1])
+    call = caller(cache)
     assert call()
-    acc = {}
     t0 = time.perf_counter()
     for _ in range(reps):
         assert call()
-        for k, v in list(cache.timings().items()) + list(cache.kernel_timings().items()):
-            acc[k] = acc.get(k, 0.0) + v / reps
     dt = (time.perf_counter() - t0) / reps
     out["ms_one_caller"] = dt * 1e3
     out["value_one_caller"] = n / dt
+    out["stage_ms_one_caller"] = {k: round(v, 3) for k, v in cache.timings().items()}
+    acc = {}
+    call_tp = caller(cache_tp)
+    assert call_tp()
+    for _ in range(reps):
+        assert call_tp()
+        for k, v in list(cache_tp.timings().items()) + list(cache_tp.kernel_timings().items()):
+            acc[k] = acc.get(k, 0.0) + v / reps
     alone = {k: v for k, v in acc.items() if k in KERNEL_BYTES}
     alone.update({KERNEL_OF_STAGE[k]: v for k, v in acc.items() if k in KERNEL_OF_STAGE})
     alone["k_sig_bucket"] = acc.get("sig_mul_sum", 0.0)

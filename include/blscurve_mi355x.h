@@ -52,9 +52,10 @@ int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* ctx, uint32_t num_threads);
 
 /* Latency mode (on = 1, the default) or throughput mode (on = 0) of a context.
  * Latency mode shortens ONE call at the price of some extra lane-work: batches of up to 8 192 sets (which do not fill the chip
- * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 11.6 ms);
- * whole-chip batches run the signature side's extra Miller pairs with 8 lanes per pair and fold the line products inside the
- * wide kernel, so that no nearly empty round of waves follows a full one.
+ * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 7.1 ms);
+ * whole-chip batches run the signature side and the Miller lines of its extra pairs on a second stream beside the hashing, so
+ * that no nearly empty round of waves follows a full one; the partial line products are folded on the lane-cooperative Fp12
+ * engine, whose workgroups have three waves in this mode.
  * Throughput mode does the least total work: for a caller that keeps several batches in flight (one context each), where
  * the nearly empty rounds of one batch overlap the wide kernels of another.  Verdicts and GT values are the same. */
 int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* ctx, int on);
