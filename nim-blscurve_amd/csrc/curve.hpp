@@ -155,6 +155,62 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     return r;
 }
 
+// Extended Jacobian coordinates ("XYZZ": x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2; infinity: ZZ = 0) for accumulators
+// that only ever take mixed additions - the Pippenger buckets: madd-2008-s is 8M + 2S where the Jacobian mixed addition above
+// is 8M + 3S (no Z1^2 to form).  Complete like jac_add_aff: infinity operands, P == Q (mdbl-2008-s-1 from the affine operand),
+// P == -Q (PP = 0 gives ZZ3 = 0).  (X ZZ, Y ZZZ, ZZ) is the same point in Jacobian coordinates: two multiplications, once per
+// bucket.
+template <class F>
+struct xyzz {
+    F x, y, zz, zzz;
+};
+template <class F>
+BLS_HD xyzz<F> xyzz_inf() { return xyzz<F>{f_zero<F>(), f_zero<F>(), f_zero<F>(), f_zero<F>()}; }
+template <class F>
+BLS_HD xyzz<F> xyzz_select(bool c, const xyzz<F>& a, const xyzz<F>& b) {
+    return xyzz<F>{f_select(c, a.x, b.x), f_select(c, a.y, b.y), f_select(c, a.zz, b.zz), f_select(c, a.zzz, b.zzz)};
+}
+template <class F>
+BLS_MID xyzz<F> xyzz_dbl_aff(const aff<F>& q) {          // q not at infinity
+    F U = f_dbl(q.y);
+    F V = f_sqr(U);
+    F W = f_mul(U, V);
+    F S = f_mul(q.x, V);
+    F XX = f_sqr(q.x);
+    F M = f_carry(f_add_nc(f_dbl_nc(XX), XX));
+    xyzz<F> r;
+    r.x = f_red(f_sub_nc(f_sqr(M), f_dbl_nc(S)));
+    r.y = f_carry(f_sub_nc(f_mul(M, f_sub_nc(S, r.x)), f_mul(W, q.y)));
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+template <class F>
+BLS_MID xyzz<F> xyzz_add_aff(const xyzz<F>& p, const aff<F>& q) {
+    bool p_inf = f_is_zero(p.zz);
+    bool q_inf = aff_is_inf(q);
+    F U2 = f_mul(q.x, p.zz);
+    F S2 = f_mul(q.y, p.zzz);
+    F P = f_sub(U2, p.x);
+    F R = f_sub(S2, p.y);
+    bool p0 = f_is_zero(P), r0 = f_is_zero(R);
+    if (!p_inf && !q_inf && p0 && r0) return xyzz_dbl_aff(q);
+    F PP = f_sqr(P);
+    F PPP = f_mul(P, PP);
+    F Q = f_mul(p.x, PP);
+    xyzz<F> r;
+    r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(R), PPP), f_dbl_nc(Q)));
+    r.y = f_carry(f_sub_nc(f_mul(R, f_sub_nc(Q, r.x)), f_mul(p.y, PPP)));
+    r.zz = f_mul(p.zz, PP);       // = 0 when P == -Q
+    r.zzz = f_mul(p.zzz, PPP);
+    r = xyzz_select(q_inf, p, r);
+    F one_or_zero = f_select(q_inf, f_zero<F>(), f_one<F>());
+    r = xyzz_select(p_inf, xyzz<F>{q.x, q.y, one_or_zero, one_or_zero}, r);
+    return r;
+}
+template <class F>
+BLS_MID jac<F> jac_from_xyzz(const xyzz<F>& p) { return jac<F>{f_mul(p.x, p.zz), f_mul(p.y, p.zzz), p.zz}; }
+
 // Jacobian + Jacobian, complete.  Out of line (jac_add_impl takes references, i.e. memory operands); callers go
 // through the by-value wrapper jac_add below so that only its private copies have their address taken and
 // the caller's own (often loop-carried) points stay in registers.

@@ -1131,14 +1131,14 @@ __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_b
     uint32_t g = g0 + (order ? order[g0 + t] : t);
     uint32_t w = g >> cbk, cnt = hist[g], off = offs[g];
     const uint32_t* srt = sorted + (size_t)w * n + off;
-    jac<F> acc = jac_inf<F>();
+    xyzz<F> acc = xyzz_inf<F>();                        // extended Jacobian: 8M + 2S per mixed addition (curve.hpp)
     for (uint32_t j = 0; j < cnt; j++) {
         uint32_t e = srt[j];
         aff<F> q = ld_aff_int(pts + (size_t)(e & 0x7fffffffu) * (2 * fld<F>::W), (const aff<F>*)nullptr);
         if (e >> 31) q.y = f_neg(q.y);
-        acc = jac_add_aff(acc, q);
+        acc = xyzz_add_aff(acc, q);
     }
-    soa_st_jac(buckets, total, g, acc);
+    soa_st_jac(buckets, total, g, jac_from_xyzz(acc));
 }
 // lane per (window, segment of L buckets): sum_{j < L} (b0 + j + 1) * B_{b0 + j}
 template <class F>

@@ -56,6 +56,17 @@ void emu_g2_dbl_team(const uint8_t* p, uint8_t* out) { g2_jac_store(out, jac_dbl
 void emu_g2_dbl(const uint8_t* p, uint8_t* out) { g2_jac_store(out, jac_dbl(g2_jac_load(p))); }
 void emu_g1_dbl_team(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl_team(g1_jac_load(p), team_solo{})); }
 void emu_g1_dbl(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl(g1_jac_load(p))); }
+// sum of n affine points (96 / 192 bytes each, all-zero = infinity) with the extended-Jacobian mixed addition of the Pippenger buckets
+void emu_g1_sum_xyzz(const uint8_t* pts, uint32_t n, uint8_t* out) {
+    xyzz<fp> acc = xyzz_inf<fp>();
+    for (uint32_t i = 0; i < n; i++) acc = xyzz_add_aff(acc, g1_aff_load(pts + 96 * i));
+    g1_jac_store(out, jac_from_xyzz(acc));
+}
+void emu_g2_sum_xyzz(const uint8_t* pts, uint32_t n, uint8_t* out) {
+    xyzz<fp2> acc = xyzz_inf<fp2>();
+    for (uint32_t i = 0; i < n; i++) acc = xyzz_add_aff(acc, g2_aff_load(pts + 192 * i));
+    g2_jac_store(out, jac_from_xyzz(acc));
+}
 // 68 lines of one pair with the team doubling step (additions as in miller_lines) against miller_lines itself: 1 = identical
 int emu_miller_lines_team_equal(const uint8_t* p144, const uint8_t* q288) {
     g1_jac pj = g1_jac_load(p144);

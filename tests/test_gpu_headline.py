@@ -53,6 +53,14 @@ def test_stage_parity_at_headline_sizes(m, n):
         assert o.g1_to_blst_affine(g1_jac_to_affine(P[144 * i:144 * i + 144])) == st["rPK"][96 * i:96 * i + 96], i
     assert o.g2_to_blst_affine(g2_jac_to_affine(cache.fetch(3, 288))) == st["aggsig"]
     assert cache.fetch(4, 576) == st["gt"]
+    # throughput mode (the contexts of bench.py's timed region: one lane per item, no fork stream, k_lineprod2 instead of
+    # the engine fold, two-wave tail): the same GT value and aggregate
+    tp = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nt)
+    tp.set_cooperative(False)
+    assert tp.verify_device(d.data_ptr(), n, RND) is True
+    assert tp.fetch(4, 576) == st["gt"]
+    assert o.g2_to_blst_affine(g2_jac_to_affine(tp.fetch(3, 288))) == st["aggsig"]
+    tp.close()
     bad = d.clone()
     i, j = n - 1, n // 2
     bad[320 * i + 128:320 * i + 320] = d[320 * j + 128:320 * j + 320]

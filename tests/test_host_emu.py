@@ -119,6 +119,21 @@ def test_scalar_mul_and_add(emu):
     assert g1_jac_to_affine(call(emu, "emu_g1_add", bytes(144), pj, outlen=144)) == p
     assert g2_jac_to_affine(call(emu, "emu_g2_add", qj, qj, outlen=288)) == o.g2_add(q, q)
     assert g2_jac_to_affine(call(emu, "emu_g2_add", qj, bytes(288), outlen=288)) == q
+    # extended-Jacobian (XYZZ) mixed addition of the Pippenger buckets: sums with every special case on the way - first
+    # operand at infinity, an affine infinity, P + P (doubling from the affine operand), P + (-P) -> infinity -> + Q
+    p2, p3 = o.g1_mul(p, 7), o.g1_mul(p, 1000003)
+    a1 = o.g1_to_blst_affine
+    for pts, want in [([p], p), ([p, p2, p3], o.g1_add(o.g1_add(p, p2), p3)), ([p, p], o.g1_add(p, p)),
+                      ([p, p, p], o.g1_mul(p, 3)), ([p, o.g1_neg(p)], None), ([p, o.g1_neg(p), p2], p2),
+                      ([None, p, None, p2], o.g1_add(p, p2)), ([None], None), ([p, p2, o.g1_add(p, p2)], o.g1_mul(o.g1_add(p, p2), 2))]:
+        raw = b"".join(a1(x) if x is not None else bytes(96) for x in pts)
+        assert g1_jac_to_affine(call(emu, "emu_g1_sum_xyzz", raw, ctypes.c_uint32(len(pts)), outlen=144)) == want
+    q2 = o.g2_mul(q, 11)
+    a2 = o.g2_to_blst_affine
+    for pts, want in [([q, q2], o.g2_add(q, q2)), ([q, q], o.g2_add(q, q)), ([q, o.g2_neg(q), q2], q2), ([None, q, None], q),
+                      ([q, q2, o.g2_add(q, q2)], o.g2_mul(o.g2_add(q, q2), 2))]:
+        raw = b"".join(a2(x) if x is not None else bytes(192) for x in pts)
+        assert g2_jac_to_affine(call(emu, "emu_g2_sum_xyzz", raw, ctypes.c_uint32(len(pts)), outlen=288)) == want
 
 
 def test_pairing_golden(emu):
