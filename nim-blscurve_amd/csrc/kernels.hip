@@ -2309,7 +2309,7 @@ static pip_win pip_plan(size_t npoints, size_t nbits) {
     while ((1ull << (lg + 1)) <= npoints) lg++;
     int c = (int)lg - 3;
     if (c < 5) c = 5;                                   // at least one 16-bucket segment per window
-    if (c > 17) c = 17;
+    if (c > 16) c = 16;                                 // at most 2^15 buckets per window: the counters of the LDS counting sort
     pip_win W{};
     W.nbits = (uint32_t)nbits;
     uint32_t ext = (uint32_t)nbits + 1;                  // one extra (zero) top bit: the top window absorbs the carry of the bias

@@ -64,7 +64,7 @@ def test_msm_vs_c_oracle(m, cache, n):
     assert cache.timings()["total"] < 40.0          # full-width random scalars must not pile up in one bucket (top-window carry)
 
 
-@pytest.mark.parametrize("n,nbits", [(40000, 255), (33000, 64), (70001, 130)])
+@pytest.mark.parametrize("n,nbits", [(40000, 255), (33000, 64), (70001, 130), (131072, 64), (100000, 256)])
 def test_msm_lds_sort_path(m, cache, n, nbits):
     """n >= 2^15: the counting sort with a window's counters in LDS (k_pip_hist_lds / k_pip_scatter_lds) and the two window
     groups; 32-byte scalar images (two 16-byte loads), blst's own (nbits + 7) / 8 spacing (8: word loads, 17: byte loads), a
