@@ -1271,16 +1271,17 @@ __global__ void __launch_bounds__(WAVE) k_sig_bucket(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ consts, uint4* __restrict__ H, uint4* __restrict__ P, size_t stride) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
     uint32_t L = 1u << lshift, g = t >> lshift, s = t & (L - 1);
-    g2_jac acc = jac_inf<fp2>();
+    xyzz<fp2> part = xyzz_inf<fp2>();                   // extended Jacobian: 8M + 2S per mixed addition (curve.hpp)
     if (g < total) {
         uint32_t w = g >> c, cnt = hist[g], off = offs[g];
         const uint32_t* srt = sorted + (size_t)w * n + off;
         for (uint32_t j = s; j < cnt; j += L) {
             const uint32_t* pw = pts + (size_t)srt[j] * (4 * FPW);
             g2_aff q{fp2{ld_fp_int(pw), ld_fp_int(pw + FPW)}, fp2{ld_fp_int(pw + 2 * FPW), ld_fp_int(pw + 3 * FPW)}};
-            acc = jac_add_aff(acc, q);
+            part = xyzz_add_aff(part, q);
         }
     }
+    g2_jac acc = jac_from_xyzz(part);
     for (uint32_t d = L >> 1; d >= 1; d >>= 1) {
         g2_jac o = shfl_down_struct(acc, (int)d);
         acc = jac_add(acc, o);
@@ -1801,7 +1802,8 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         k_msm_scan<<<nwin, WAVE, 0, ss>>>(hist, cw, offs, cursor);
         k_msm_scatter<<<dim3(nb, nwin), WAVE, 0, ss>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, cursor, c->d_sig_sorted);
         uint32_t per = n32 >> cw, lshift = 0;                          // expected entries per bucket; ~16 per lane
-        while (lshift < 6 && (per >> (lshift + 1)) >= 16) lshift++;
+        const uint32_t per_lane_min = c->coop ? 16u : 64u;      // throughput mode: fewer, longer lanes (the fold of a bucket's lanes is pure overhead)
+        while (lshift < 6 && (per >> (lshift + 1)) >= per_lane_min) lshift++;
         // small batches leave most of the chip idle: more lanes per bucket (down to ~2 entries per lane) shorten the kernel
         while (lshift < 6 && ((total << (lshift + 1)) <= 16 * c->slots) && (per >> (lshift + 1)) >= 2) lshift++;
         k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, ss>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,

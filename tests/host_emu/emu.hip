@@ -142,7 +142,7 @@ unsigned long long emu_mad_census(int stage, const uint8_t* set320, uint64_t r) 
         case 0: hash_to_field_fp2x2(u0, u1, set320 + 96, 32, dst, sizeof(dst) - 1); (void)iso3_g2(sswu_g2(u0)); (void)iso3_g2(sswu_g2(u1)); break;
         case 1: (void)clear_cofactor_g2(jac_add(q0, q1)); break;
         case 2: (void)jac_mul_u64_w4(g1_aff_load(set320), r); break;
-        case 3: { g2_aff s2 = g2_aff_load(set320 + 128); g2_jac acc = jac_from_aff(sg); acc = jac_dbl(acc); for (int i = 0; i < 8; i++) acc = jac_add_aff(acc, s2); } break;
+        case 3: { g2_aff s2 = g2_aff_load(set320 + 128); xyzz<fp2> acc = xyzz_dbl_aff(sg); g_mad_count = 0; for (int i = 0; i < 8; i++) acc = xyzz_add_aff(acc, s2); } break;      // 8 mixed additions (one per 8-bit window) onto a bucket that is neither infinity nor the point itself
         case 4: miller_lines(rp, h, [&](int, const line_t&) {}); break;
         case 5: { fp12 f = fp12_from_line(L[0]); for (int s = 0; s < N_LINES; s++) f = fp12_mul_by_line(f, L[s]); } break;
     }
