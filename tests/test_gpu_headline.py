@@ -131,3 +131,29 @@ def test_one_blocking_call_above_the_headline(m, n):
     bad[320 * 200001:320 * 200001 + 96] = 0
     assert cache.verify_device(bad.data_ptr(), n, RND) is False
     cache.close()
+
+
+@pytest.mark.parametrize("n", [8192, 8193, 16384, 16385, 39999, 40000])
+def test_gt_parity_at_the_path_boundaries(m, n):
+    """The sizes where run_shard changes path: 8 192 / 8 193 (8 lanes per set -> one lane per set), 16 384 / 16 385 ([r]PK and
+    the signature side on the fork stream -> only the signature side and its extra pairs' lines), 39 999 / 40 000 (4-bit ->
+    8-bit signature buckets).  Latency and throughput mode: GT and aggregate bit-exact against the C restatement, one
+    context reused across a true and a false batch."""
+    import c_oracle as co
+    d = _signed_records(m, n, first=13_000_000)
+    rec = bytes(d.cpu().numpy())
+    nt = 4096
+    ok, st = co.batch_verify(rec, RND, nt, stages=True)
+    assert ok
+    bad = d.clone()
+    bad[320 * (n - 1) + 96] ^= 1                                        # last message: the signature no longer matches
+    for coop in (True, False):
+        cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nt)
+        cache.set_cooperative(coop)
+        assert cache.verify_device(d.data_ptr(), n, RND) is True
+        assert cache.fetch(4, 576) == st["gt"], coop
+        assert o.g2_to_blst_affine(g2_jac_to_affine(cache.fetch(3, 288))) == st["aggsig"]
+        assert cache.verify_device(bad.data_ptr(), n, RND) is False
+        assert cache.verify_device(d.data_ptr(), n, RND) is True
+        assert cache.fetch(4, 576) == st["gt"]
+        cache.close()
