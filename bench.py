@@ -48,6 +48,7 @@ MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 26308
                  "k_lineprod": 1039584}
 MAD_ISSUE_CYCLES = 4.0          # one wave64 VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md, issue cost table)
 CLOCK_HZ = 2.4e9                # peak engine clock; under this load the chip sustains less (DVFS), see DESIGN.md section 4
+MAD_PEAK_MEASURED = 256 * 4 * 64 / 2.28e-9      # multiply-adds/s the chip issues in the micro-benchmark (profiles/r01_ubench_valu.txt)
 # which stage timer (HIP events inside the library) measures which single kernel
 KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
 
@@ -327,7 +328,12 @@ def main():
                                      "model": "census of the kernels' formulas (MAD_PER_TUPLE) x tuples / ms_per_step; peak = CUs x 4 SIMDs x 64 lanes x "
                                               "2.4 GHz / 4 cycles per v_mad_i64_i32",
                                      "per_kernel_frac_alone": {k: MAD_PER_TUPLE[k] * n / (alone[k] * 1e-3) / mad_peak
-                                                               for k in alone if k in MAD_PER_TUPLE}},
+                                                               for k in alone if k in MAD_PER_TUPLE},
+                                     "peak_measured": MAD_PEAK_MEASURED / 1e12,
+                                     "frac_of_measured": mad_achieved / MAD_PEAK_MEASURED,
+                                     "peak_measured_note": "tools/ubench_valu.hip on this chip (profiles/r01_ubench_valu.txt): a stream of independent "
+                                                           "v_mad_u64_u32 issues one per 2.28 ns per SIMD at 4 waves per SIMD (2.41 at 8, 2.87 at 1), "
+                                                           "not one per 4 cycles at 2.4 GHz = 1.67 ns"},
                          "note": "the path is integer multiply-add bound, not HBM bound (1.2e4 multiply-adds per input byte): int_mad is the roofline "
                                  "that says how good the kernels are; the HBM fraction is reported because the contract asks for it"},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
