@@ -240,3 +240,51 @@ def test_sizes_beyond_one_wave_per_simd(m, n):
     if rec[320 * i + 128:320 * i + 320] != rec[320 * j + 128:320 * j + 320]:
         assert m.batchVerify(cache, bytes(bad), rnd) is False
     cache.close()
+
+
+def test_randomised_batches_against_the_c_oracle(m):
+    """Soak: 40 batches of random size (1 .. 700) on ONE reused context, each with a random defect or none - duplicated tuples
+    (equal points meet in a signature bucket: the doubling case of the mixed addition), an all-zero signature or public key, a
+    flipped message / key / signature bit, signatures swapped between tuples - both modes, random numThreads: verdict and, for
+    batches the oracle accepts or rejects alike, the GT value equal to the C restatement's."""
+    import random
+    import c_oracle as co
+    rng = random.Random(20261003)
+    caches = {True: m.BatchedBLSVerifierCache.init(max_sets=700, numThreads=64), False: m.BatchedBLSVerifierCache.init(max_sets=700, numThreads=64)}
+    caches[False].set_cooperative(False)
+    pool = co.make_batch(700, seed=424242)
+    for it in range(40):
+        n = rng.choice([1, 2, 3, 5, 8, 63, 64, 65, 100, 257, 700, rng.randrange(1, 700)])
+        idx = [rng.randrange(700) for _ in range(n)] if it % 3 == 0 else rng.sample(range(700), n)     # with / without duplicates
+        rec = bytearray(b"".join(pool[320 * i:320 * i + 320] for i in idx))
+        defect = rng.choice(["none", "none", "msg", "pk", "sig", "swap", "inf_sig", "inf_pk"])
+        t = rng.randrange(n)
+        if defect == "msg":
+            rec[320 * t + 96 + rng.randrange(32)] ^= 1 << rng.randrange(8)
+        elif defect == "pk" and n > 1:
+            u = (t + 1) % n
+            rec[320 * t:320 * t + 96] = rec[320 * u:320 * u + 96]
+        elif defect == "sig" and n > 1:
+            u = (t + 1) % n
+            rec[320 * t + 128:320 * t + 320] = rec[320 * u + 128:320 * u + 320]
+        elif defect == "swap" and n > 1:
+            u = (t + 1) % n
+            a, b = bytes(rec[320 * t + 128:320 * t + 320]), bytes(rec[320 * u + 128:320 * u + 320])
+            rec[320 * t + 128:320 * t + 320], rec[320 * u + 128:320 * u + 320] = b, a
+        elif defect == "inf_sig":
+            rec[320 * t + 128:320 * t + 320] = bytes(192)
+        elif defect == "inf_pk":
+            rec[320 * t:320 * t + 96] = bytes(96)
+        rec = bytes(rec)
+        rnd = o.sha256(b"soak" + bytes([it]))
+        nt = rng.choice([1, 4, 64, 4096])
+        want, st = co.batch_verify(rec, rnd, nt if (nt > 1 and n >= 3) else 0, stages=True)       # batchVerify's own choice of the serial chain
+        for coop, cache in caches.items():
+            cache.numThreads = nt
+            m._check(m.lib().mi355_bls_ctx_set_num_threads(cache._h, nt))
+            got = m.batchVerify(cache, rec, rnd)
+            assert got == want, (it, n, defect, nt, coop)
+            if defect != "inf_pk":
+                assert cache.fetch(4, 576) == st["gt"], (it, n, defect, nt, coop)
+    for c in caches.values():
+        c.close()
