@@ -416,6 +416,28 @@ def pmc_traffic(kernel):
 
 
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
+def compress_records(recs):
+    """SignatureSet records (blst Montgomery images, R = 2^384) -> ZCash compressed keys (48 B) and signatures (96 B):
+    big-endian x with the flag bits 0x80 (compressed) and 0x20 (y is the lexicographically larger root).  Host-side input
+    preparation of the fromBytes row (plain integers, no library code)."""
+    rinv = pow(1 << 384, -1, P_MOD)
+    fe = lambda b: int.from_bytes(b, "little") * rinv % P_MOD
+    pks, sgs = [], []
+    for i in range(len(recs) // 320):
+        r = recs[320 * i:320 * i + 320]
+        x, y = fe(r[0:48]), fe(r[48:96])
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if y > (P_MOD - 1) // 2 else 0)
+        pks.append(bytes(b))
+        x0, x1, y0, y1 = fe(r[128:176]), fe(r[176:224]), fe(r[224:272]), fe(r[272:320])
+        big = (y1 > (P_MOD - 1) // 2) if y1 else (y0 > (P_MOD - 1) // 2)
+        b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if big else 0)
+        sgs.append(bytes(b))
+    return b"".join(pks), b"".join(sgs)
 
 
 def secret_key(i):
@@ -470,6 +492,25 @@ def aux_rows(m, cache, dev):
         assert v1() == 1
     out["verify_one_signature"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3}
     rnd = hashlib.sha256(b"Mr F was here").digest()
+    # row f1: PublicKey.fromBytes + Signature.fromBytes for every tuple of a 65 536-tuple batch (compressed wire format resident in
+    # HBM): decompression (one Fp / one Fp2 square root), "not infinity", both subgroup checks
+    nd = 65536
+    recs = bytes(sign_records(m, cache, dev, range(4096)).cpu().numpy())
+    pk48, sg96 = compress_records(recs)
+    d_pk = torch.frombuffer(bytearray(pk48 * (nd // 4096)), dtype=torch.uint8).to(dev)
+    d_sg = torch.frombuffer(bytearray(sg96 * (nd // 4096)), dtype=torch.uint8).to(dev)
+    d_ms = torch.frombuffer(bytearray(b"".join(recs[320 * i + 96:320 * i + 128] for i in range(4096)) * (nd // 4096)), dtype=torch.uint8).to(dev)
+    back = ctypes.create_string_buffer(320 * 4096)
+    deser = lambda out: m._check(m.lib().mi355_bls_deserialize_sets_device(cache._h, d_pk.data_ptr(), d_ms.data_ptr(), d_sg.data_ptr(), nd, 0, out, None))
+    assert m._check(m.lib().mi355_bls_deserialize_sets_device(cache._h, d_pk.data_ptr(), d_ms.data_ptr(), d_sg.data_ptr(), 4096, 0, back, None)) == 1
+    assert back.raw == recs                                            # the records the signer produced, byte for byte
+    assert deser(None) == 1
+    acc = 0.0
+    for _ in range(5):
+        assert deser(None) == 1
+        acc += cache.timings()["total"] / 5
+    out["fromBytes_65536"] = {"ms_per_call": acc, "tuples_per_s": nd / (acc * 1e-3),
+                              "note": "kernel time (k_deser), compressed keys / messages / signatures and the 320-byte records resident in HBM"}
     # a 64-set batch (the size of one beacon block's signature sets): latency
     d64 = sign_records(m, cache, dev, range(64))
     c64 = m.BatchedBLSVerifierCache.init(max_sets=64, device=dev.index or 0)
@@ -680,6 +721,17 @@ def cpu_baseline(co, sample, rnd):
     co.msm_g1_pippenger(mp, sc, 255)
     dtm = time.perf_counter() - t0
     legs["config4_g1_msm"] = {"points_per_s": nm / dtm, "cores": use, "sample": "2^16 of the 2^20 points, nbits 255, Pippenger restatement with windows on OpenMP threads, %.1f s" % dtm}
+    # row f1: fromBytes of every tuple (decompression, not-infinity, subgroup checks), the restatement's OpenMP loop over the tuples
+    nf = 64 * use
+    recs = co.make_batch(nf, seed=1 << 41)
+    pk48, sg96 = compress_records(recs)
+    ms = b"".join(recs[320 * i + 96:320 * i + 128] for i in range(nf))
+    t0 = time.perf_counter()
+    okd, back, _ = co.deserialize_sets(pk48, ms, sg96)
+    dtf = time.perf_counter() - t0
+    assert okd and back == recs
+    legs["f1_fromBytes"] = {"tuples_per_s": nf / dtf, "cores": use,
+                            "sample": "%d tuples; the restatement tests subgroup membership as [r]P = O (BLST uses the endomorphism tests, several times cheaper)" % nf}
     out["legs"] = legs
     return out
 
