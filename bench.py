@@ -511,6 +511,28 @@ def aux_rows(m, cache, dev):
         acc += cache.timings()["total"] / 5
     out["fromBytes_65536"] = {"ms_per_call": acc, "tuples_per_s": nd / (acc * 1e-3),
                               "note": "kernel time (k_deser), compressed keys / messages / signatures and the 320-byte records resident in HBM"}
+    # row f2: MultiSignatureSet.combine of 4 096 signatures on one message = a G1 and a G2 Pippenger run with 64-bit scalars (host arrays in)
+    nc = 4096
+    same = bytes(sign_records(m, cache, dev, range(nc), msgs=[msg] * nc).cpu().numpy())
+    cpk = b"".join(same[320 * i:320 * i + 96] for i in range(nc))
+    csg = b"".join(same[320 * i + 128:320 * i + 320] for i in range(nc))
+    opk, osg = ctypes.create_string_buffer(96), ctypes.create_string_buffer(192)
+    comb = lambda: m._check(m.lib().mi355_bls_combine(cache._h, rnd, cpk, csg, nc, opk, osg))
+    comb()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        comb()
+    out["combine_4096"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3}
+    assert m.batchVerify(cache, opk.raw + msg + osg.raw, rnd) is True          # the combined set verifies
+    # row f3: the batch signer (publicFromSecret + coreSign per tuple; variable time: inputs of tests and benches only)
+    sk_t = torch.frombuffer(bytearray(b"".join(secret_key(i).to_bytes(32, "little") for i in range(65536))), dtype=torch.uint8).to(dev)
+    ms_t = torch.frombuffer(bytearray(b"".join(hashlib.sha256(b"msg" + str(i).encode()).digest() for i in range(65536))), dtype=torch.uint8).to(dev)
+    o_t = torch.zeros(320 * 65536, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    oks, _ = m.signSets_device(cache, sk_t.data_ptr(), ms_t.data_ptr(), 65536, o_t.data_ptr())
+    out["batch_signer_65536"] = {"ms_per_call": (time.perf_counter() - t0) * 1e3}
+    assert oks
     # a 64-set batch (the size of one beacon block's signature sets): latency
     d64 = sign_records(m, cache, dev, range(64))
     c64 = m.BatchedBLSVerifierCache.init(max_sets=64, device=dev.index or 0)

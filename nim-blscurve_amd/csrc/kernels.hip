@@ -1542,6 +1542,7 @@ struct mi355_bls_ctx {
     xmd32_consts xmd;                // message-independent SHA-256 words of expand_message_xmd for this DST
     std::vector<uint64_t> h_r;       // host-computed scalar chains (serial blinding chain, combine)
     msm_ws* msm = nullptr;           // lazily sized MSM workspace
+    msm_ws* msm2 = nullptr;          // a second one: combine runs its G1 and its G2 Pippenger side by side
 };
 
 constexpr uint32_t SIG_SLOTS_MAX = 2048;     // 8 windows x 256 digits
@@ -1565,6 +1566,10 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (c->ev_lp) (void)hipEventDestroy(c->ev_lp);
     if (c->ev_deser0) (void)hipEventDestroy(c->ev_deser0);
     if (c->ev_deser1) (void)hipEventDestroy(c->ev_deser1);
+    if (c->msm2) {
+        msm_free(c->msm2);
+        delete c->msm2;
+    }
     if (c->msm) {
         msm_free(c->msm);
         delete c->msm;
@@ -1576,6 +1581,7 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
 static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     c->device = device;
     c->msm = new msm_ws();
+    c->msm2 = new msm_ws();
     c->cap = max_sets;
     c->stride = ((max_sets + 1 + SIG_SLOTS_MAX + 63) / 64) * 64;          // tuple pairs + the extra pair(s) of the signature side
     std::memset(&c->dst, 0, sizeof(c->dst));
@@ -2337,8 +2343,8 @@ extern "C" size_t mi355_bls_p1s_mult_pippenger_scratch_sizeof(size_t npoints) {
 }
 
 // workspace for npoints points of `affb`-byte affine images (96: G1, 192: G2) under window plan W
-static int msm_reserve(mi355_bls_ctx* c, size_t n, const pip_win& W, size_t affb) {
-    msm_ws* m = c->msm;
+static int msm_reserve(mi355_bls_ctx* c, msm_ws* m, size_t n, const pip_win& W, size_t affb) {
+    (void)c;
     uint32_t total = W.nwin << W.cbk;
     size_t pts_bytes = n * affb;
     if (pts_bytes <= m->cap_n && total <= m->cap_total) return 0;
@@ -2379,23 +2385,15 @@ static int msm_reserve(mi355_bls_ctx* c, size_t n, const pip_win& W, size_t affb
     return 0;
 }
 
-// sum_i [k_i mod 2^nbits] P_i on the device.  sbytes: distance between scalars (32 for blst_scalar images; blst's own
-// convention is (nbits + 7) / 8).  ret: blst_p1 (144 B) or blst_p2 (288 B), host memory.
+// Everything up to the result in m->out (blst_p1 / blst_p2 image, device memory) is ENQUEUED on `st` with workspace m; nothing is
+// waited for.  timed: record the context's stage events.  allow_split: the window groups may use the context's side stream.
 template <class F>
-static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits, void* stream) {
-    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192, JACB = AFFB / 2 * 3;
-    if (!c || !ret || nbits == 0 || nbits > 256 || npoints > (1u << 28) || (size_t)sbytes * 8 < nbits || sbytes > 32) return MI355_BLS_ERR_ARG;
-    if (npoints == 0) {
-        memset(ret, 0, JACB);
-        return 0;
-    }
-    if (!d_points || !d_scalars) return MI355_BLS_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(c->device));
+static int msm_enqueue(mi355_bls_ctx* c, msm_ws* m, const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits,
+                       hipStream_t st, bool timed, bool allow_split) {
+    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192;
     pip_win W = pip_plan(npoints, nbits);
-    int rc = msm_reserve(c, npoints, W, AFFB);
+    int rc = msm_reserve(c, m, npoints, W, AFFB);
     if (rc) return rc;
-    msm_ws* m = c->msm;
     uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, seg = W.cbk >= 12 ? 8u : MSM_SEG, segs_per_win = (1u << W.cbk) / seg,      // shorter running sums once they still fill the chip
              nseg = nw * segs_per_win;
     const uint8_t* pts = (const uint8_t*)d_points;
@@ -2437,14 +2435,14 @@ static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t 
     };
     HIPCHK(hipMemsetAsync(m->hist, 0, (size_t)total * 4, st));
     HIPCHK(hipMemsetAsync(m->chist, 0, 4 * 256 * 4, st));
-    HIPCHK(hipEventRecord(c->ev[0], st));
+    if (timed) HIPCHK(hipEventRecord(c->ev[0], st));
     k_pip_convert<F><<<nbp, WAVE, 0, st>>>(pts, n, m->pts_int);
     // The counting sort covers all windows; then two groups of windows, each on its own stream: the HIGH windows first (their
     // results need the long doubling chains: up to nbits - c dependent doublings on one wave per window, ~1 ms of pure
     // latency), the LOW windows' bucket kernel behind the high one, so that the high group's serial tail runs beside the bucket
     // accumulation of the low group and only the short chains of the low windows are left at the end.  More groups lose more
     // in the bucket kernels' tails than they hide.  Large inputs only: a small MSM is latency-bound in every stage.
-    const bool split = c->side && nw >= 4 && (size_t)n * nw >= ((size_t)1 << 22);
+    const bool split = allow_split && c->side && nw >= 4 && (size_t)n * nw >= ((size_t)1 << 22);
     uint32_t cut[3] = {nw, 0, 0}, ngroups = 1;                      // groups [cut[g + 1], cut[g]), from the high windows down
     if (split) {
         cut[1] = nw / 2;
@@ -2456,23 +2454,40 @@ static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t 
     hipEvent_t gev[2] = {m->ev_fork, m->ev_bucketed};
     count_sort(0, nw, st);
     for (uint32_t g = 0; g < ngroups; g++) order_group(cut[g + 1], cut[g], g, st);
-    HIPCHK(hipEventRecord(c->ev[1], st));
+    if (timed) HIPCHK(hipEventRecord(c->ev[1], st));
     for (uint32_t g = 0; g < ngroups; g++) {
         if (g) HIPCHK(hipStreamWaitEvent(gs[g], gev[g - 1], 0));
         bucket_group(cut[g + 1], cut[g], gs[g]);
         HIPCHK(hipEventRecord(gev[g], gs[g]));
-        if (g == 0) HIPCHK(hipEventRecord(c->ev[2], st));
+        if (g == 0 && timed) HIPCHK(hipEventRecord(c->ev[2], st));
         reduce_group(cut[g + 1], cut[g], gs[g]);
-        if (g == 0) HIPCHK(hipEventRecord(c->ev[3], st));
+        if (g == 0 && timed) HIPCHK(hipEventRecord(c->ev[3], st));
     }
     for (uint32_t g = 1; g < ngroups; g++) {
         HIPCHK(hipEventRecord(gev[g], gs[g]));
         HIPCHK(hipStreamWaitEvent(st, gev[g], 0));
     }
     k_pip_final<F><<<1, WAVE, 0, st>>>(m->winout, nw, m->out);
-    HIPCHK(hipEventRecord(c->ev[4], st));
+    if (timed) HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ret, m->out, JACB, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+// sum_i [k_i mod 2^nbits] P_i on the device.  sbytes: distance between scalars (32 for blst_scalar images; blst's own
+// convention is (nbits + 7) / 8).  ret: blst_p1 (144 B) or blst_p2 (288 B), host memory.
+template <class F>
+static int msm_run(mi355_bls_ctx* c, uint8_t* ret, const void* d_points, size_t npoints, const void* d_scalars, uint32_t sbytes, size_t nbits, void* stream) {
+    constexpr size_t JACB = (sizeof(F) == sizeof(fp) ? 96 : 192) / 2 * 3;
+    if (!c || !ret || nbits == 0 || nbits > 256 || npoints > (1u << 28) || (size_t)sbytes * 8 < nbits || sbytes > 32) return MI355_BLS_ERR_ARG;
+    if (npoints == 0) {
+        memset(ret, 0, JACB);
+        return 0;
+    }
+    if (!d_points || !d_scalars) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = msm_enqueue<F>(c, c->msm, d_points, npoints, d_scalars, sbytes, nbits, st, true, true);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ret, c->msm->out, JACB, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return collect_timings(c, 4);       // [0] sort, [1] bucket accumulation, [2] segment reduction, [3] window sums + doublings
 }
@@ -2491,7 +2506,7 @@ static int msm_host(mi355_bls_ctx* c, uint8_t* ret, const uint8_t* pts, size_t n
     constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192;
     if (!c || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    int rc = msm_reserve(c, npoints, pip_plan(npoints, nbits), AFFB);
+    int rc = msm_reserve(c, c->msm, npoints, pip_plan(npoints, nbits), AFFB);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->msm->d_pts, pts, npoints * AFFB, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(c->msm->d_sc, scalars, npoints * sbytes, hipMemcpyHostToDevice, nullptr));
@@ -2750,26 +2765,30 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
     host_combine_chain(rnd, n, c->h_r.data());
     HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), n * 8, hipMemcpyHostToDevice, st));
     // the reference's two 64-bit Pippenger calls (core :629-646): 8-byte scalars, nbits = 64
-    uint8_t p1[144], p2[288];
-    int rc = msm_run<fp>(c, p1, d_pk, n, c->d_r, 8, 64, st);
+    // The two runs are independent: G1 on the caller's stream, G2 on the context's side stream with a workspace of its own, results
+    // left on the device for `finish`; one synchronisation at the end (two blocking calls in a row: 7.2 ms at n = 4096).
+    hipStream_t s2 = c->side ? c->side : st;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    if (s2 != st) HIPCHK(hipStreamWaitEvent(s2, c->ev[0], 0));            // the staged inputs
+    int rc = msm_enqueue<fp2>(c, c->msm2, d_sg, n, c->d_r, 8, 64, s2, false, false);
     if (rc) return rc;
-    float t_g1 = c->timings[7];
-    rc = msm_run<fp2>(c, p2, d_sg, n, c->d_r, 8, 64, st);
+    HIPCHK(hipEventRecord(c->ev[2], s2));
+    rc = msm_enqueue<fp>(c, c->msm, d_pk, n, c->d_r, 8, 64, st, false, s2 == st);
     if (rc) return rc;
-    float t_g2 = c->timings[7];
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    if (s2 != st) HIPCHK(hipStreamWaitEvent(st, c->ev[2], 0));
     // `finish` (to affine, core :172-177)
-    HIPCHK(hipMemcpyAsync(c->d_agg1, p1, 144, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_agg, p2, 288, hipMemcpyHostToDevice, st));
     uint32_t* d_out = reinterpret_cast<uint32_t*>(c->d_msg);
-    k_finish_affine<<<1, 1, 0, st>>>(c->d_agg1, c->d_agg, d_out, d_out + 24);
+    k_finish_affine<<<1, 1, 0, st>>>(c->msm->out, c->msm2->out, d_out, d_out + 24);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], st));
     HIPCHK(hipMemcpyAsync(out_pk, d_out, 96, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_sig, d_out + 24, 192, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 8; i++) c->timings[i] = 0;
-    c->timings[1] = t_g1;             // G1 Pippenger
-    c->timings[2] = t_g2;             // G2 Pippenger
-    c->timings[7] = t_g1 + t_g2;
+    HIPCHK(hipEventElapsedTime(&c->timings[1], c->ev[0], c->ev[1]));       // G1 Pippenger
+    HIPCHK(hipEventElapsedTime(&c->timings[2], c->ev[0], c->ev[2]));       // G2 Pippenger (beside it)
+    HIPCHK(hipEventElapsedTime(&c->timings[7], c->ev[0], c->ev[3]));
     c->last_n = n;                  // fetch_stage(0) returns the combine scalars
     return 0;
 }
