@@ -419,6 +419,20 @@ R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
 
+def g2_jacobian_image_to_affine(p288):
+    """blst_p2 image (Jacobian X, Y, Z over Fp2, Montgomery R = 2^384) -> blst_p2_affine image (192 B).  Plain integers: input
+    preparation of the aggregateVerify row."""
+    rinv = pow(1 << 384, -1, P_MOD)
+    f = [int.from_bytes(p288[48 * i:48 * i + 48], "little") * rinv % P_MOD for i in range(6)]
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P_MOD, (a[0] * b[1] + a[1] * b[0]) % P_MOD)
+    X, Y, Z = (f[0], f[1]), (f[2], f[3]), (f[4], f[5])
+    nz = pow((Z[0] * Z[0] + Z[1] * Z[1]) % P_MOD, -1, P_MOD)
+    zi = (Z[0] * nz % P_MOD, -Z[1] * nz % P_MOD)
+    zi2 = mul(zi, zi)
+    x, y = mul(X, zi2), mul(Y, mul(zi2, zi))
+    return b"".join((v * (1 << 384) % P_MOD).to_bytes(48, "little") for v in (x[0], x[1], y[0], y[1]))
+
+
 def compress_records(recs):
     """SignatureSet records (blst Montgomery images, R = 2^384) -> ZCash compressed keys (48 B) and signatures (96 B):
     big-endian x with the flag bits 0x80 (compressed) and 0x20 (y is the lexicographically larger root).  Host-side input
@@ -524,6 +538,18 @@ def aux_rows(m, cache, dev):
         comb()
     out["combine_4096"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3}
     assert m.batchVerify(cache, opk.raw + msg + osg.raw, rnd) is True          # the combined set verifies
+    # row f4: aggregateVerify of ONE aggregate signature over 1 024 (public key, message) pairs with distinct messages
+    na = 1024
+    ra = bytes(sign_records(m, cache, dev, range(na)).cpu().numpy())
+    apk = [ra[320 * i:320 * i + 96] for i in range(na)]
+    ams = [ra[320 * i + 96:320 * i + 128] for i in range(na)]
+    asum = m.blst_p2s_mult_pippenger(b"".join(ra[320 * i + 128:320 * i + 320] for i in range(na)), b"\x01" * na, 8)      # sum of the signatures
+    asig = g2_jacobian_image_to_affine(asum)
+    assert m.aggregateVerify(cache, apk, ams, asig) is True
+    t0 = time.perf_counter()
+    for _ in range(5):
+        assert m.aggregateVerify(cache, apk, ams, asig) is True
+    out["aggregateVerify_1024"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3, "note": "host arrays in (Python list handling included)"}
     # row f3: the batch signer (publicFromSecret + coreSign per tuple; variable time: inputs of tests and benches only)
     sk_t = torch.frombuffer(bytearray(b"".join(secret_key(i).to_bytes(32, "little") for i in range(65536))), dtype=torch.uint8).to(dev)
     ms_t = torch.frombuffer(bytearray(b"".join(hashlib.sha256(b"msg" + str(i).encode()).digest() for i in range(65536))), dtype=torch.uint8).to(dev)

@@ -1378,6 +1378,12 @@ __global__ void __launch_bounds__(WAVE) k_hash_var(const uint8_t* __restrict__ m
     g2_jac h = hash_to_g2(msgs + offs[i], offs[i + 1] - offs[i], dst.b, dst.len);
     soa_st_g2(H, stride, i, h);
 }
+// 32-byte messages, packed -> offset 96 of 320-byte records (the layout k_hash_map reads); the other bytes are not read
+__global__ void __launch_bounds__(WAVE) k_aggv_records(const uint8_t* __restrict__ msgs, uint32_t n, uint8_t* __restrict__ recs) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < 32; j++) recs[(size_t)i * 320 + 96 + j] = msgs[(size_t)i * 32 + j];
+}
 // pairs 0..n-1: P = pk_i (affine, Z = 1); pair n: (P, Q) = (-G1, sig)
 __global__ void __launch_bounds__(WAVE) k_aggv_setup(const uint8_t* __restrict__ pks, uint32_t n, const uint32_t* __restrict__ sig, uint4* __restrict__ H,
                                                      uint4* __restrict__ P, size_t stride, uint32_t* __restrict__ flags) {
@@ -1753,6 +1759,35 @@ static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipS
     }
 }
 
+// The per-step products of the Miller lines of pairs 0 .. npairs-1 -> d_L (68 step products).  mid_ev: recorded between the wide
+// kernel and the fold of its partials.
+static int enqueue_line_products(mi355_bls_ctx* c, uint32_t npairs, hipStream_t st, hipEvent_t mid_ev) {
+    uint32_t nblk = c->slots / N_LINES;
+    if (nblk < 1) nblk = 1;
+    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
+    uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
+    if (m < 1) m = 1;
+    nblk = (npairs + WAVE * m - 1) / (WAVE * m);
+    // every lane hands its partial product over (64 x nblk per step).  Throughput mode: k_lineprod2's 68 waves fold them,
+    // 15 sequential Fp12 products per lane + one shuffle tree (least total work); latency mode: k_fold on the lane-cooperative
+    // engine, 64 per block and then the nblk block results (one caller, 65 536 tuples: 1.8 -> 0.35 ms)
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, 1);
+    if (mid_ev) HIPCHK(hipEventRecord(mid_ev, st));
+    if (c->coop) {
+        size_t first_last = (size_t)(nblk - 1) * WAVE * m;             // lanes past the last pair hold 1: not folded
+        uint32_t live = (nblk - 1) * WAVE + (npairs - first_last < WAVE ? (uint32_t)(npairs - first_last) : WAVE);
+        uint32_t per = 1;                                              // two levels of about sqrt(live) dependent products each
+        while (per * per < live) per++;
+        uint32_t nb1 = (live + per - 1) / per;
+        uint32_t* mid = c->d_lpart + (size_t)N_LINES * c->nblk_cap * WAVE * F12W;
+        k_fold<<<dim3(N_LINES, nb1), TAIL_THREADS, 0, st>>>(c->d_lpart, nblk * WAVE, per, live - (nb1 - 1) * per, nb1 > 1 ? mid : c->d_L);
+        if (nb1 > 1) k_fold<<<dim3(N_LINES, 1), TAIL_THREADS, 0, st>>>(mid, nb1, nb1, nb1, c->d_L);
+    } else {
+        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk * WAVE, c->d_L);
+    }
+    return 0;
+}
+
 // Enqueues everything up to the shard's committed state (d_states slot 0).  n = local tuple count.
 // The three producers of Miller pairs are independent until the lines: hashing (k_hash_map, k_hash_clear), [r]PK (k_pkmul) and
 // the signature side (bucket fold).  A batch that fills the chip runs them one after the other on the caller's stream (each is a
@@ -1832,28 +1867,9 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         launch_lines(c, npairs, total, st);
     }
     HIPCHK(hipEventRecord(c->ev[5], st));
-    uint32_t nblk = c->slots / N_LINES;
-    if (nblk < 1) nblk = 1;
-    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
-    uint32_t m = (npairs + WAVE * nblk - 1) / (WAVE * nblk);
-    if (m < 1) m = 1;
-    nblk = (npairs + WAVE * m - 1) / (WAVE * m);
-    // every lane hands its partial product over (64 x nblk per step).  Throughput mode: k_lineprod2's 68 waves fold them,
-    // 15 sequential Fp12 products per lane + one shuffle tree (least total work); latency mode: k_fold on the lane-cooperative
-    // engine, 64 per block and then the nblk block results (one caller, 65 536 tuples: 1.8 -> 0.35 ms)
-    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, 1);
-    HIPCHK(hipEventRecord(c->ev_lp, st));
-    if (c->coop) {
-        size_t first_last = (size_t)(nblk - 1) * WAVE * m;             // lanes past the last pair hold 1: not folded
-        uint32_t live = (nblk - 1) * WAVE + (npairs - first_last < WAVE ? (uint32_t)(npairs - first_last) : WAVE);
-        uint32_t per = 1;                                              // two levels of about sqrt(live) dependent products each
-        while (per * per < live) per++;
-        uint32_t nb1 = (live + per - 1) / per;
-        uint32_t* mid = c->d_lpart + (size_t)N_LINES * c->nblk_cap * WAVE * F12W;
-        k_fold<<<dim3(N_LINES, nb1), TAIL_THREADS, 0, st>>>(c->d_lpart, nblk * WAVE, per, live - (nb1 - 1) * per, nb1 > 1 ? mid : c->d_L);
-        if (nb1 > 1) k_fold<<<dim3(N_LINES, 1), TAIL_THREADS, 0, st>>>(mid, nb1, nb1, nb1, c->d_L);
-    } else {
-        k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk * WAVE, c->d_L);
+    {
+        int rcp = enqueue_line_products(c, npairs, st, c->ev_lp);
+        if (rcp) return rcp;
     }
     c->wide_recorded = true;
     HIPCHK(hipEventRecord(c->ev[6], st));
@@ -2817,22 +2833,31 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
     uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE, nb1 = (n32 + 1 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
-    k_hash_var<<<nb, WAVE, 0, st>>>(d_msgs, d_off, n32, c->dst, c->d_H, c->stride);
+    bool all32 = c->xmd.valid;                      // every message 32 bytes long (signing roots): the batch path's hashing kernels
+    for (size_t i = 0; i < n && all32; i++) all32 = msg_offsets[i + 1] - msg_offsets[i] == 32;
+    if (all32) {
+        // k_hash_map reads the message at offset 96 of a 320-byte record: the 32-byte messages are spread to that layout on the device
+        // side of the staging buffer (keys | offsets | messages are packed at its start; the records go to d_comp)
+        k_aggv_records<<<nb, WAVE, 0, st>>>(d_msgs, n32, c->d_comp);
+        k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_comp, n32, c->dst, c->xmd, c->d_M, c->mstride);
+        if (c->coop && (n32 + 7) / 8 <= c->slots)
+            k_hash_clear_coop<<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+        else
+            k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+    } else {
+        k_hash_var<<<nb, WAVE, 0, st>>>(d_msgs, d_off, n32, c->dst, c->d_H, c->stride);
+    }
     HIPCHK(hipEventRecord(c->ev[1], st));
     k_aggv_setup<<<nb1, WAVE, 0, st>>>(d_pk, n32, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
     launch_lines(c, n32 + 1, 0, st);
     HIPCHK(hipEventRecord(c->ev[3], st));
-    uint32_t np = n32 + 1, nblk = c->slots / N_LINES;
-    if (nblk < 1) nblk = 1;
-    if (nblk > c->nblk_cap) nblk = c->nblk_cap;
-    uint32_t mm = (np + WAVE * nblk - 1) / (WAVE * nblk);
-    if (mm < 1) mm = 1;
-    nblk = (np + WAVE * mm - 1) / (WAVE * mm);
-    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, np, c->stride, mm, c->d_lpart, nblk, 0);
-    k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, nblk, c->d_L);
+    {
+        int rcp = enqueue_line_products(c, n32 + 1, st, nullptr);
+        if (rcp) return rcp;
+    }
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipGetLastError());
     uint32_t fl[2];
