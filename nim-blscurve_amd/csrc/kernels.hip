@@ -2020,7 +2020,7 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
     if (!c || !fp12s || kk == 0 || kk > 64) return MI355_BLS_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_states, fp12s, kk * 576, hipMemcpyHostToDevice, nullptr));
-    k_tail<<<1, TAIL_THREADS, 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, nullptr>>>(c->d_L, c->d_states, (uint32_t)kk, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipGetLastError());
     uint32_t v = 0;
     HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
@@ -2300,7 +2300,7 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     k_lineprod<<<dim3(N_LINES, 1), WAVE, 0, st>>>(c->d_lines, 2, c->stride, 1, c->d_lpart, 1, 0);
     k_lineprod2<<<N_LINES, WAVE, 0, st>>>(c->d_lpart, 1, c->d_L);
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, TAIL_THREADS, 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     uint32_t fl[2];
     HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
