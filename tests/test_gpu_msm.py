@@ -45,6 +45,20 @@ def test_msm_edges(m, cache):
     K2 = [(1 << 256) - 1] * 7
     P2 = [P[0]] * 5 + [None, P[1]]
     assert g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts2, sc2, 255)) == o.msm_g1(P2, K2, 255)
+    # points ON THE CURVE BUT OUTSIDE G1 (blst's Pippenger does not ask for subgroup membership, and nothing here may assume it:
+    # no endomorphism decomposition): x -> y = sqrt(x^3 + 4), order a multiple of the cofactor
+    rng = random.Random(77)
+    outside = []
+    while len(outside) < 9:
+        x = rng.randrange(o.P)
+        rhs = (x * x * x + 4) % o.P
+        y = pow(rhs, (o.P + 1) // 4, o.P)
+        if y * y % o.P == rhs and o.g1_mul((x, y), o.R) is not None:
+            outside.append((x, y))
+    ks = [rng.getrandbits(255) for _ in outside]
+    raw = b"".join(o.g1_to_blst_affine(q) for q in outside)
+    got = g1_jac_to_affine(m.p1s_mult_pippenger(cache, raw, b"".join(k.to_bytes(32, "little") for k in ks), 255))
+    assert got == o.msm_g1(outside, ks, 255)
     # cancellation: k*P + k*(-P) = inf
     neg = o.g1_to_blst_affine(o.g1_neg(P[0]))
     assert g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts[:96] + neg, sc[:32] * 2, 255)) is None
