@@ -114,6 +114,18 @@ struct team_solo {
     }
     template <class F>
     BLS_HD F mul1(const F& a, const F& b) const { return f_mul(a, b); }
+    template <class F>
+    BLS_HD void mul2(F& r0, F& r1, const F& a0, const F& b0, const F& a1, const F& b1) const {
+        r0 = f_mul(a0, b0); r1 = f_mul(a1, b1);
+    }
+    template <class F>
+    BLS_HD void sqr2(F& r0, F& r1, const F& a0, const F& a1) const {
+        r0 = f_sqr(a0); r1 = f_sqr(a1);
+    }
+    template <class F>
+    BLS_HD void mul4(F& r0, F& r1, F& r2, F& r3, const F& a0, const F& b0, const F& a1, const F& b1, const F& a2, const F& b2, const F& a3, const F& b3) const {
+        r0 = f_mul(a0, b0); r1 = f_mul(a1, b1); r2 = f_mul(a2, b2); r3 = f_mul(a3, b3);
+    }
 };
 template <class F, class Team>
 BLS_MID jac<F> jac_dbl_team(const jac<F>& p, const Team& team) {
@@ -244,6 +256,36 @@ template <class F>
 BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) { return jac_add_body(p, q); }
 template <class F>
 BLS_HD jac<F> jac_add(jac<F> p, jac<F> q) { return jac_add_impl(p, q); }
+
+// Lane-cooperative complete addition (the formulas, carries and reductions of jac_add_body; products by the Team): five rounds
+//   Z1^2, Z2^2  |  X1 Z2Z2, X2 Z1Z1, Y1 Z2, Y2 Z1  |  (Y1 Z2) Z2Z2, (Y2 Z1) Z1Z1, Z1 Z2, H^2  |  H HH, U1 HH, (Z1 Z2) H, r^2  |  r (V - X3), S1 HHH
+// instead of sixteen multiplications in a row on every lane.  P == Q falls through to the team doubling.
+template <class F, class Team>
+BLS_MID jac<F> jac_add_team(const jac<F>& p, const jac<F>& q, const Team& team) {
+    bool p_inf = jac_is_inf(p);
+    bool q_inf = jac_is_inf(q);
+    F Z1Z1, Z2Z2;
+    team.sqr2(Z1Z1, Z2Z2, p.z, q.z);
+    F U1, U2, T1, T2;
+    team.mul4(U1, U2, T1, T2, p.x, Z2Z2, q.x, Z1Z1, p.y, q.z, q.y, p.z);
+    F H = f_sub(U2, U1);
+    F S1, S2, Z12, HH;
+    team.mul4(S1, S2, Z12, HH, T1, Z2Z2, T2, Z1Z1, p.z, q.z, H, H);
+    F rr = f_sub(S2, S1);
+    bool h0 = f_is_zero(H), r0 = f_is_zero(rr);
+    if (!p_inf && !q_inf && h0 && r0) return jac_dbl_team(p, team);
+    F HHH, V, Z3, RR;
+    team.mul4(HHH, V, Z3, RR, H, HH, U1, HH, Z12, H, rr, rr);
+    jac<F> r;
+    r.x = f_red(f_sub_nc(f_sub_nc(RR, HHH), f_dbl_nc(V)));
+    F A, B;
+    team.mul2(A, B, rr, f_sub_nc(V, r.x), S1, HHH);
+    r.y = f_carry(f_sub_nc(A, B));
+    r.z = Z3;
+    r = jac_select(q_inf, p, r);
+    r = jac_select(p_inf, q, r);
+    return r;
+}
 
 // [k]P for a 64-bit scalar, affine base; left-to-right double-and-add.  Not constant time: the
 // blinding scalars are public (blst_min_pubkey_sig_core.nim:531-541 rationale).

@@ -228,8 +228,10 @@ struct g2_park_regs {
 // accumulator a plain loop-carried value: inlined into the kernel it lives in registers for the whole chain (as the return
 // value of an out-of-line [x]-multiplication it lived in scratch memory and was stored back 84 words per doubling).
 // dbl: the doubling of the chain (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
-template <class Pt, class Park, class Dbl>
-BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl) {
+// add_in: the additions inside the chain (accumulator + parked base); add: the others.  The one-lane-per-point kernels pass the
+// inlined body / the out-of-line addition, the kernels with a team of lanes per point the lane-cooperative jac_add_team.
+template <class Pt, class Park, class Dbl, class AddIn, class Add>
+BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl, AddIn&& add_in, Add&& add) {
     Pt base = p, u = p, res = p;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < 2; pass++) {
@@ -238,20 +240,24 @@ BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl) {
 #pragma clang loop unroll(disable)
         for (int i = 62; i >= 0; i--) {
             acc = dbl(acc);
-            if ((k::X_ABS >> i) & 1) acc = jac_add_body(acc, park.get());
+            if ((k::X_ABS >> i) & 1) acc = add_in(acc, park.get());
         }
         acc = jac_neg(acc);                                  // x < 0
         if (pass == 0) {
             Pt t2 = g2_psi(p);
-            u = jac_add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));            // psi^2(2P) - psi(P)
-            u = jac_add(u, jac_neg(acc));                                // - [x]P
-            u = jac_add(u, jac_neg(p));                                  // - P
-            base = jac_add(acc, t2);                                     // [x]P + psi(P)
+            u = add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));                // psi^2(2P) - psi(P)
+            u = add(u, jac_neg(acc));                                    // - [x]P
+            u = add(u, jac_neg(p));                                      // - P
+            base = add(acc, t2);                                         // [x]P + psi(P)
         } else {
-            res = jac_add(u, acc);
+            res = add(u, acc);
         }
     }
     return res;
+}
+template <class Pt, class Park, class Dbl>
+BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl) {
+    return clear_cofactor_g2_with(p, park, dbl, [](const Pt& a, const Pt& b) { return jac_add_body(a, b); }, [](const Pt& a, const Pt& b) { return jac_add(a, b); });
 }
 template <class Park>
 BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {

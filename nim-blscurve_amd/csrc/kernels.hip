@@ -331,6 +331,13 @@ struct team_lanes8 {
         r0 = gather3(v, 0); r1 = gather3(v, 1); r2 = gather3(v, 2);
     }
     __device__ __forceinline__ fp2 mul1(const fp2& a, const fp2& b) const { return gather3(half_mul(a, b), 0); }
+    // four products, eight halves: every lane of the team multiplies
+    __device__ __forceinline__ void mul4(fp2& r0, fp2& r1, fp2& r2, fp2& r3, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2,
+                                         const fp2& a3, const fp2& b3) const {
+        const uint32_t q = role >> 1;
+        fp v = half_mul(fp2_select(q < 2, fp2_select(q == 0, a0, a1), fp2_select(q == 2, a2, a3)), fp2_select(q < 2, fp2_select(q == 0, b0, b1), fp2_select(q == 2, b2, b3)));
+        r0 = gather3(v, 0); r1 = gather3(v, 1); r2 = gather3(v, 2); r3 = gather3(v, 3);
+    }
     __device__ __forceinline__ void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
         fp2 r = fp2_sqr(fp2_select(role == 0, a0, fp2_select(role == 1, a1, fp2_select(role == 2, a2, fp2_select(role == 3, a3, a4)))));
         r0 = fp2_from_role(r, gbase, 0); r1 = fp2_from_role(r, gbase, 1); r2 = fp2_from_role(r, gbase, 2);
@@ -359,8 +366,10 @@ __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, u
 __device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
     g2_park_regs park;
     team_lanes8 team{gbase, role};
-    return clear_cofactor_g2_with(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); });
+    auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
+    return clear_cofactor_g2_with(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
 }
+__device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
 // their independent products over roles 0..2.  Every group of 8 lanes does the same work.
@@ -371,7 +380,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
     g2_jac q = iso3_g2(sswu_g2(fp2_select(role == 1, u1, u0)));
     g2_jac q0{fp2_from_role(q.x, gbase, 0), fp2_from_role(q.y, gbase, 0), fp2_from_role(q.z, gbase, 0)};
     g2_jac q1{fp2_from_role(q.x, gbase, 1), fp2_from_role(q.y, gbase, 1), fp2_from_role(q.z, gbase, 1)};
-    g2_jac h = clear_cofactor_g2_coop(jac_add(q0, q1), gbase, role);
+    g2_jac h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
     if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, h);
 }
 // batch form for batches that would not fill the chip with one lane per message: 8 lanes per message
@@ -381,7 +390,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restric
     bool live = i < n;
     if (!live) i = 0;
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
-    g2_jac h = clear_cofactor_g2_coop(jac_add(q0, q1), gbase, role);
+    g2_jac h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
     if (live && role == 0) soa_st_g2(H, stride, i, h);
 }
 

@@ -54,6 +54,7 @@ void emu_g2_mul_256_jac(const uint8_t* p, const uint8_t* k32, uint8_t* out) {
 // the lane-cooperative formulas with the solo team (every product computed here): must equal the plain ones
 void emu_g2_dbl_team(const uint8_t* p, uint8_t* out) { g2_jac_store(out, jac_dbl_team(g2_jac_load(p), team_solo{})); }
 void emu_g2_dbl(const uint8_t* p, uint8_t* out) { g2_jac_store(out, jac_dbl(g2_jac_load(p))); }
+void emu_g2_add_team(const uint8_t* a, const uint8_t* b, uint8_t* out) { g2_jac_store(out, jac_add_team(g2_jac_load(a), g2_jac_load(b), team_solo{})); }
 void emu_g1_dbl_team(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl_team(g1_jac_load(p), team_solo{})); }
 void emu_g1_dbl(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl(g1_jac_load(p))); }
 // sum of n affine points (96 / 192 bytes each, all-zero = infinity) with the extended-Jacobian mixed addition of the Pippenger buckets

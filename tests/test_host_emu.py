@@ -349,3 +349,9 @@ def test_team_formulas_equal_the_plain_ones(emu):
             assert g1_jac_to_affine(a) == g1_jac_to_affine(b)
             P = a
         assert emu.emu_miller_lines_team_equal(P, Q) == 1
+        # the team addition: general position (non-trivial Z on both sides), P + P, P + (-P), infinity on either side
+        q2 = o.g2_mul(o.G2_GEN, rng.randrange(1, o.R))
+        Q2 = call(emu, "emu_g2_dbl", g2_aff_to_jac_bytes(q2), outlen=288)
+        for A, B in ((Q, Q2), (Q2, Q), (Q, Q), (Q, g2_aff_to_jac_bytes(o.g2_neg(g2_jac_to_affine(Q)))), (bytes(288), Q), (Q, bytes(288))):
+            a, b = call(emu, "emu_g2_add_team", A, B, outlen=288), call(emu, "emu_g2_add", A, B, outlen=288)
+            assert g2_jac_to_affine(a) == g2_jac_to_affine(b)
