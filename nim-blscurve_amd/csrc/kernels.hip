@@ -411,8 +411,8 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
 // k_lines_coop: the Miller lines of FEW pairs (up to 8 per wave): 8 lanes share one pair and split the independent
 // products of every doubling step (the 63 of the 68 steps): 5 squarings, then 2 squarings, then 2 products, then the
 // 6 Fp products of the line scaling, each group as ONE multiplier call with per-lane operands - about 4 multiplication
-// times per step instead of 15.  Same formulas, carries and reductions as miller_dbl_step; the 5 addition steps run
-// redundantly in every lane.  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.9 ms).
+// times per step instead of 15.  Same formulas, carries and reductions as miller_dbl_step; the 5 addition steps likewise
+// (miller_add_step_team: six rounds).  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.8 ms).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ line_t miller_dbl_step_coop(g2_proj& t, const g1_pre& p, uint32_t gbase, uint32_t role) {
     return miller_dbl_step_team(t, p, team_lanes8{gbase, role});
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P
 #pragma clang loop unroll(disable)
     for (int bit = 62; bit >= 0; bit--) {
         sink(miller_dbl_step_coop(t, p, gbase, role));
-        if ((k::X_ABS >> bit) & 1) sink(miller_add_step(t, q, p));
+        if ((k::X_ABS >> bit) & 1) sink(miller_add_step_team(t, q, p, team_lanes8{gbase, role}));
     }
 }
 

@@ -83,7 +83,7 @@ int emu_miller_lines_team_equal(const uint8_t* p144, const uint8_t* q288) {
     for (int bit = 62; bit >= 0; bit--) {
         line_t l = miller_dbl_step_team(t, p, team_solo_miller{});
         same &= eq(l, ref[s++]);
-        if ((k::X_ABS >> bit) & 1) { line_t a = miller_add_step(t, q, p); same &= eq(a, ref[s++]); }
+        if ((k::X_ABS >> bit) & 1) { line_t a = miller_add_step_team(t, q, p, team_solo_miller{}); same &= eq(a, ref[s++]); }
     }
     return same;
 }
