@@ -285,7 +285,9 @@ def main():
                 cache_tp.set_cooperative(False)
             one = one_caller_rows(m, cache, cache_tp, streams[0], d_sets, n, n_total, lo, hi, rnd, sharded_path)
         alone = one["kernel_alone_ms"]
-        dom = max(alone, key=lambda k: alone[k])                   # the dominant single kernel, by its un-overlapped duration
+        if not any(k in KERNEL_BYTES for k in alone):              # --threads with --no-one-caller records no stage timers
+            alone = {"k_lineprod": ms_per_step}
+        dom = max((k for k in alone if k in KERNEL_BYTES), key=lambda k: alone[k])      # the dominant single kernel, by its un-overlapped duration
         alg_bytes = KERNEL_BYTES[dom] * n
         dom_ms = timed_kernel_ms.get(dom, alone[dom])
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
