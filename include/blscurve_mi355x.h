@@ -52,7 +52,7 @@ int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* ctx, uint32_t num_threads);
 
 /* Latency mode (on = 1, the default) or throughput mode (on = 0) of a context.
  * Latency mode shortens ONE call at the price of some extra lane-work: batches of up to 8 192 sets (which do not fill the chip
- * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 7.1 ms);
+ * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 6.8 ms);
  * whole-chip batches run the signature side and the Miller lines of its extra pairs on a second stream beside the hashing, so
  * that no nearly empty round of waves follows a full one; the partial line products are folded on the lane-cooperative Fp12
  * engine, whose workgroups have three waves in this mode.
