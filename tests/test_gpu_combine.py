@@ -127,3 +127,32 @@ def test_g2_pippenger_lds_sort_path(m):
             sc = b"".join(sc[32 * i:32 * i + 31] + bytes([sc[32 * i + 31] & 0x7f]) for i in range(n))
         got = m.blst_p2s_mult_pippenger(pts, sc, nbits)
         assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == co.msm_g2(pts, sc, nbits, sb), (n, nbits)
+
+
+def test_g2_pippenger_linearity_at_2_18(m):
+    """G2 MSM large enough for the two window groups on two streams (n x windows >= 2^22) on top of the LDS counting sort:
+    MSM(k) + MSM(k') == MSM(k + k') on the same 2^18 points (scalars below 2^254), checked with the big-int oracle's group law."""
+    import random
+    import numpy as np
+    import c_oracle as co
+    from util import g2_jac_to_affine
+    rng = random.Random(9)
+    n = 1 << 18
+    h = co.hash_to_g2(b"g2 msm 2^18", o.DST_SIG)
+    base = [co.g2_mul(h, rng.randrange(1, o.R)) for _ in range(256)]
+    pts = b"".join(base[i % 256] for i in range(n))
+    ra = np.random.default_rng(3)
+    k1 = ra.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k2 = ra.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k1[:, 31] &= 0x3f
+    k2[:, 31] &= 0x3f
+    s = np.zeros((n, 32), dtype=np.uint8)
+    carry = np.zeros(n, dtype=np.uint16)
+    for j in range(32):
+        t = k1[:, j].astype(np.uint16) + k2[:, j].astype(np.uint16) + carry
+        s[:, j] = (t & 0xff).astype(np.uint8)
+        carry = t >> 8
+    a = g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, k1.tobytes(), 255))
+    b = g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, k2.tobytes(), 255))
+    c = g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, s.tobytes(), 255))
+    assert o.g2_add(a, b) == c and c is not None
