@@ -9,7 +9,9 @@
 set -e
 cd "$(dirname "$0")"
 OUT=${BLS_OUT:-libblscurve_mi355x.so}
-if [ "$1" != "-f" ] && [ -f $OUT ] && [ -z "$(find csrc ../include tools/align_isa.py build.sh -newer $OUT -type f)" ]; then
+# up to date = the library was built from exactly these sources (content hash, not time stamps: a copy of the tree need not keep them)
+STAMP=$(cat csrc/* ../include/*.h tools/align_isa.py build.sh | sha256sum | cut -d" " -f1)-$BLS_EXTRA_FLAGS
+if [ "$1" != "-f" ] && [ -f $OUT ] && [ "$(cat $OUT.stamp 2>/dev/null)" = "$STAMP" ]; then
   exit 0
 fi
 LLVM=/opt/rocm/lib/llvm/bin
@@ -32,3 +34,4 @@ if [ "$BLS_NO_ALIGN" = "1" ] || ! aligned_build; then
   hipcc $FLAGS -fPIC -shared csrc/kernels.hip -o $OUT.tmp
 fi
 mv $OUT.tmp $OUT
+echo "$STAMP" > $OUT.stamp
