@@ -256,6 +256,14 @@ def main():
             except Exception:
                 pass
         assert runner(max(a.warmup, 0), False), "warm-up batch must verify"
+    if sharded_path and world > 1:
+        # every rank must run the same exchange: if any rank fell back to the host exchange, all do
+        flag = torch.tensor([1 if exchange["mode"] == "device" else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and exchange["mode"] == "device":
+            exchange["mode"] = "host"
+            exchange["fallback"] = "another rank fell back to the host exchange"
+            assert runner(max(a.warmup, 0), False), "warm-up batch must verify"
     sync()
     t0 = time.perf_counter()
     ok = runner(a.steps, True)
