@@ -338,7 +338,7 @@ def main():
                                      "model": "census of the kernels' formulas (MAD_PER_TUPLE) x tuples / ms_per_step; peak = CUs x 4 SIMDs x 64 lanes x "
                                               "2.4 GHz / 4 cycles per v_mad_i64_i32",
                                      "per_kernel_frac_alone": {k: MAD_PER_TUPLE[k] * n / (alone[k] * 1e-3) / mad_peak
-                                                               for k in alone if k in MAD_PER_TUPLE},
+                                                               for k in alone if k in MAD_PER_TUPLE and alone[k] > 0},
                                      "peak_measured": MAD_PEAK_MEASURED / 1e12,
                                      "frac_of_measured": mad_achieved / MAD_PEAK_MEASURED,
                                      "peak_measured_note": "tools/ubench_valu.hip on this chip (profiles/r01_ubench_valu.txt): a stream of independent "
