@@ -53,6 +53,318 @@ MAD_PEAK_MEASURED = 256 * 4 * 64 / 2.28e-9      # multiply-adds/s the chip issue
 KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(a):
+    """`bench.py --gpus N` without a launcher: this process starts N rank processes itself (one per GPU, torchrun-style
+    environment) BEFORE it makes any GPU call of its own, relays rank 0's one JSON line and fails if any rank fails.
+    (Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks already exist: WORLD_SIZE is set and this is skipped.)"""
+    import subprocess
+    n = a.gpus
+    have = torch.cuda.device_count()                 # counts devices without initialising the GPU
+    if have < n and os.environ.get("BENCH_ALL_ON_DEVICE0") != "1":
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) are visible\n" % (n, have))
+        return 2
+    ge.build(load=False)                             # compile once here, not N times in the ranks
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    out0 = []
+    th = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in list(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+        time.sleep(0.05)
+    if failed is not None:
+        for r in live:                               # exactly the processes started above
+            procs[r].kill()
+        for pr in procs:
+            pr.wait()
+        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        return 1
+    th.join(10)
+    lines = [l for l in "".join(out0).splitlines() if l.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def next_rnd(rnd):
+    """secureRandomBytes of the next step: re-hashed before every iteration as benchmarks/bls_signature.nim:269-275 does."""
+    return hashlib.sha256(rnd).digest()
+
+
+class ShardedRun:
+    """One configuration of the timed loop: `inflight` caller contexts on this rank's GPU, n tuples per GPU per step."""
+
+    def __init__(self, m, a, dev, local, rank, world, backend, ctl, n, sharded_path):
+        self.m, self.a, self.dev, self.rank, self.world, self.backend, self.ctl, self.n, self.sharded_path = m, a, dev, rank, world, backend, ctl, n, sharded_path
+        # caller streams first: HIP spreads streams over its hardware queues as they are created, and two callers
+        # whose streams share a hardware queue run strictly one after the other (seen with rocprofv3 --kernel-trace)
+        self.inflight = inflight = max(1, a.inflight)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
+        t0 = time.time()
+        # n distinct valid (pk, SHA256("msg"+i), sig) tuples made by the library's own device signer
+        # (mi355_bls_sign_sets_device; parity-tested against the oracle in tests/test_gpu_sign.py)
+        gen = m.BatchedBLSVerifierCache.init(max_sets=n, device=local)
+        self.d_sets = sign_records(m, gen, dev, range(rank * n, rank * n + n))
+        gen.close()
+        self.gen_s = time.time() - t0
+        self.n_total = n * world
+        self.nthreads = nthreads = m.DEFAULT_NUM_THREADS * world                # global number of blinding chains
+        # `inflight` independent callers (one context + stream each, "one context per concurrent caller",
+        # bls_batch_verifier.nim:389-391) keep several batches in flight so that one batch's serial tail
+        # (step products, Horner, final exponentiation: a handful of waves) overlaps another batch's wide kernels.
+        self.caches = [m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local) for _ in range(inflight)]
+        self.throughput_mode = a.ctx_mode == "throughput" or (a.ctx_mode == "auto" and inflight > 1)
+        for c in self.caches:
+            c.set_cooperative(not self.throughput_mode)  # throughput mode: several batches in flight (include/blscurve_mi355x.h)
+        self.fv_caches = [m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=nthreads, device=local) for _ in range(inflight)] if sharded_path else []
+        self.lo, self.hi, first, count = m.shard_plan(self.n_total, nthreads, world, rank)
+        assert count == n
+        self.exchange = {"mode": a.exchange if backend == "nccl" else "host"}
+        self.gathered = [torch.zeros(world * 640, dtype=torch.uint8, device=dev) for _ in range(inflight)] if sharded_path else []
+        # every context writes its shard blob straight into a torch tensor: the send buffer of the collective
+        self.mine_t = [torch.zeros(640, dtype=torch.uint8, device=dev) for _ in range(inflight)] if sharded_path else []
+        for c, t in zip(self.caches, self.mine_t):
+            c.set_shard_blob_ptr(t.data_ptr())
+        self.stage_acc = {}
+        self.fv_busy = [False] * inflight
+        self.rnd_of_slot = [None] * inflight
+
+    def close(self):
+        for c in self.caches + self.fv_caches:
+            c.close()
+        self.d_sets = None
+
+    def all_gather_host(self, blob):
+        """host exchange: over the gloo control group, so that it still works when the RCCL transport is what failed"""
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        allst = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allst, mine, group=self.ctl)
+        return [bytes(t.numpy().tobytes()) for t in allst]
+
+    def record_timings(self, c):
+        for kk, v in list(c.timings().items()) + list(c.kernel_timings().items()):
+            self.stage_acc[kk] = self.stage_acc.get(kk, 0.0) + v
+
+    def submit(self, slot, after, rnd):
+        c, st = self.caches[slot], self.streams[slot]
+        if not self.sharded_path:
+            c.submit_device(self.d_sets.data_ptr(), self.n, rnd, st.cuda_stream, after=after)
+        else:
+            c.shard_submit_device(self.d_sets.data_ptr(), self.n_total, self.lo, self.hi, rnd, st.cuda_stream, after=after)
+
+    def fv_drain(self, slot):
+        """Verdict of the merge + final exponentiation enqueued for this slot one round ago (rank 0)."""
+        if not self.fv_busy[slot]:
+            return True
+        self.fv_busy[slot] = False
+        return self.fv_caches[slot].finalverify_wait()
+
+    def collect(self, slot, record):
+        c, st = self.caches[slot], self.streams[slot]
+        if not self.sharded_path:
+            res = c.wait()
+        elif self.exchange["mode"] == "device":
+            # The bench SYNCHRONISES on the shard (shard_wait: a host wait + 580-byte D2H) before it issues the collective: torch
+            # enqueues collectives on a stream of its own, and a collective that had to wait there for a whole batch would block the
+            # hardware queue it shares with a caller stream (measured: 18.3 instead of 13.5 ms per step when the all_gather is enqueued
+            # right behind the submit).  The all_gather itself runs on device buffers (RCCL over xGMI); merge + final exponentiation
+            # (rank 0) are enqueued behind it and their verdict is read one round later (fv_drain), so the host never waits for them
+            # while other batches are in flight.
+            res = self.fv_drain(slot)
+            state, okf = c.shard_wait()
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(self.gathered[slot], self.mine_t[slot])
+            if self.rank == 0:
+                self.fv_caches[slot].finalverify_blobs_submit(self.gathered[slot].data_ptr(), self.world, 640, st.cuda_stream)
+                self.fv_busy[slot] = True
+        else:
+            state, okf = c.shard_wait()
+            blobs = self.all_gather_host(state + bytes([1 if okf else 0]) + bytes(7))
+            res = True
+            if self.rank == 0:
+                res = all(b[576] == 1 for b in blobs) and self.fv_caches[slot].finalverify_shards([b[:576] for b in blobs])
+        if record:
+            self.record_timings(c)
+        return res
+
+    def run_steps(self, k, record, rnd):
+        """One host thread keeps `inflight` batches in flight with the submit / wait entry points (context
+        i % inflight; a context is waited for right before it is reused, i.e. oldest first).  Every batch is
+        chained to the one submitted before it (`after`): it starts when that one has finished hashing and its public-key
+        multiplications, so the batches in flight sit at different stages and a serial tail always runs beside whole-chip
+        kernels of another batch.  secureRandomBytes is re-hashed before every step (benchmarks/bls_signature.nim:269-275).
+        Returns (every verdict true, rnd after the last step)."""
+        ok = True
+        inflight, caches = self.inflight, self.caches
+        busy = [False] * inflight
+        for it in range(k):
+            slot = it % inflight
+            if busy[slot]:
+                ok = self.collect(slot, record) and ok
+            # chaining staggers whole-chip batches; small batches do not fill the chip and simply run side by side
+            after = caches[(slot - 1) % inflight] if (inflight > 1 and self.n >= 32768) else None
+            rnd = next_rnd(rnd)
+            self.submit(slot, after, rnd)
+            busy[slot] = True
+        for j in range(inflight):
+            slot = (k + j) % inflight
+            if busy[slot]:
+                ok = self.collect(slot, record) and ok
+                busy[slot] = False
+        for slot in range(inflight):
+            ok = self.fv_drain(slot) and ok
+        return ok, rnd
+
+    def run_steps_threads(self, k, record, rnd):
+        """--threads: one blocking call per host thread (N = 1 only)."""
+        from concurrent.futures import ThreadPoolExecutor
+        import queue
+        free = queue.Queue()
+        for i in range(self.inflight):
+            free.put(i)
+        rnds = []
+        for _ in range(k):
+            rnd = next_rnd(rnd)
+            rnds.append(rnd)
+
+        def one(r):
+            slot = free.get()
+            try:
+                return self.caches[slot].verify_device(self.d_sets.data_ptr(), self.n, r, self.streams[slot].cuda_stream)
+            finally:
+                free.put(slot)
+        with ThreadPoolExecutor(max_workers=self.inflight) as pool:
+            return all(pool.map(one, rnds)), rnd
+
+    def reset_after_transport_error(self):
+        torch.cuda.synchronize()
+        for i in range(self.inflight):
+            self.fv_busy[i] = False
+        for c in self.caches + self.fv_caches:
+            for fn in (c.shard_wait, c.finalverify_wait):
+                try:
+                    fn()
+                except Exception:
+                    pass
+
+    def timed(self, steps, warmup):
+        """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns the max over ranks (s)."""
+        a, world, backend, dev = self.a, self.world, self.backend, self.dev
+        runner = self.run_steps_threads if (a.threads and not self.sharded_path) else self.run_steps
+        rnd = hashlib.sha256(b"Mr F was here").digest()
+
+        def sync():
+            if self.sharded_path:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # Warm-up.  Only a TRANSPORT error of the device-side exchange (RCCL all_gather on device buffers) makes the run fall back
+        # to the host exchange, and only after all ranks agreed on it over the gloo control group; a wrong verdict never does: it
+        # fails the run.
+        err = None
+        ok = True
+        try:
+            ok, rnd_w = runner(max(warmup, 0), False, rnd)
+        except (RuntimeError, dist.DistBackendError) as e:
+            if not (self.sharded_path and self.exchange["mode"] == "device"):
+                raise
+            err = e
+        if self.sharded_path and self.exchange["mode"] == "device":
+            flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.ctl)
+            if int(flag.item()) == 0:
+                self.exchange["mode"] = "host"
+                self.exchange["fallback"] = ("device-side exchange failed on this rank (%s: %s); host exchange used" % (type(err).__name__, str(err)[:200])
+                                             if err is not None else "another rank's device-side exchange failed; host exchange used")
+                self.reset_after_transport_error()
+                ok, rnd_w = runner(max(warmup, 0), False, rnd)
+        assert ok, "a warm-up batch did not verify"
+        sync()
+        t0 = time.perf_counter()
+        ok, _ = runner(steps, True, rnd_w)
+        sync()
+        dt = time.perf_counter() - t0
+        assert ok, "a timed batch did not verify"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if self.sharded_path:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+
+def msm_rows_sharded(m, cache, dev, rank, world, backend, ctl):
+    """G1 MSM points/s on N GPUs (BASELINE.json's second metric), point-sharded: every rank computes the
+    full-width partial of its points and leaves it in device memory, ONE all_gather of 144 bytes per rank, rank 0 adds the
+    partials.  weak: 2^20 points per GPU (the config-4 shape per device); strong: 2^20 points in all."""
+    import numpy as np
+    out = {}
+    nm = 1 << 20
+    msg = hashlib.sha256(b"Mr F was here").digest()
+    import random
+    rng = random.Random(7 + rank)
+    base = sign_records(m, cache, dev, range(2048), sks=[rng.getrandbits(96) | 1 for _ in range(2048)], msgs=[msg] * 2048)
+    dp = base.view(2048, 320)[:, :96].contiguous().repeat(nm // 2048, 1).reshape(-1)     # P_i = [a_i]G1, a_i 96-bit
+    ds = torch.frombuffer(bytearray(np.random.default_rng(7 + rank).integers(0, 256, size=(nm, 32), dtype=np.uint8).tobytes()), dtype=torch.uint8).to(dev)
+    part = torch.zeros(144, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(144 * world, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+
+    def one(npts):
+        m.p1s_mult_pippenger_partial_device(cache, part.data_ptr(), dp.data_ptr(), npts, ds.data_ptr(), 255, st.cuda_stream)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, part)
+        else:
+            lst = [torch.empty(144, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(lst, part.cpu(), group=ctl)
+            gathered.copy_(torch.cat(lst).to(dev))
+        if rank == 0:
+            return m.p1s_add_device(cache, gathered.data_ptr(), world, 144, st.cuda_stream)
+        torch.cuda.synchronize()
+        return None
+
+    for name, npts in (("weak_2^20_per_gpu", nm), ("strong_2^20_total", m.msm_shard_range(nm, world, rank)[1])):
+        res = one(npts)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            res = one(npts)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tm = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=ctl)
+        dt = float(tm.item())
+        total = nm * world if name.startswith("weak") else nm
+        out[name] = {"points_per_s": total / dt, "ms_per_call": dt * 1e3, "points_total": total, "nbits": 255, "result_is_point": res is None or len(res) == 144}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,21 +384,32 @@ def main():
                     help="N > 1: all_gather of device-resident shard blobs (RCCL, no host round trip) or of host bytes")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))                 # this process never touches the GPU: the ranks are its children
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N does so itself; under "
+                         "torch.distributed.run pass --nproc-per-node N and --gpus N)\n" % (a.gpus, world))
+        sys.exit(2)
     # BENCH_DIST_BACKEND=gloo + BENCH_ALL_ON_DEVICE0=1 is a TEST HOOK: it lets the N > 1 code path (sharding, exchange,
     # merge) run end to end on a box with a single GPU; real runs use RCCL ("nccl") with one GPU per rank.
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if os.environ.get("BENCH_ALL_ON_DEVICE0") == "1":
         local = 0
     sharded_path = world > 1 or a.force_dist
+    ctl = None
     if sharded_path:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        # control group over gloo: agreement on the exchange mode and the host exchange must not depend on the RCCL transport
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -94,187 +417,15 @@ def main():
     m = ge.load_package()
 
     n = a.batch
-    # caller streams first: HIP spreads streams over its hardware queues as they are created, and two callers
-    # whose streams share a hardware queue run strictly one after the other (seen with rocprofv3 --kernel-trace)
-    inflight = max(1, a.inflight)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
-    t0 = time.time()
-    # n distinct valid (pk, SHA256("msg"+i), sig) tuples made by the library's own device signer
-    # (mi355_bls_sign_sets_device; parity-tested against the oracle in tests/test_gpu_sign.py)
-    gen = m.BatchedBLSVerifierCache.init(max_sets=n, device=local)
-    d_sets = sign_records(m, gen, dev, range(rank * n, rank * n + n))
-    del gen
-    gen_s = time.time() - t0
+    run = ShardedRun(m, a, dev, local, rank, world, backend, ctl, n, sharded_path)
+    inflight, streams, caches, d_sets = run.inflight, run.streams, run.caches, run.d_sets
+    n_total, nthreads, lo, hi, throughput_mode = run.n_total, run.nthreads, run.lo, run.hi, run.throughput_mode
     rnd = hashlib.sha256(b"Mr F was here").digest()
-
-    n_total = n * world
-    nthreads = m.DEFAULT_NUM_THREADS * world                # global number of blinding chains
-    # `inflight` independent callers (one context + stream each, "one context per concurrent caller",
-    # bls_batch_verifier.nim:389-391) keep several batches in flight so that one batch's serial tail
-    # (step products, Horner, final exponentiation: a handful of waves) overlaps another batch's wide kernels.
-    caches = [m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local) for _ in range(inflight)]
-    throughput_mode = a.ctx_mode == "throughput" or (a.ctx_mode == "auto" and inflight > 1)
-    for c in caches:
-        c.set_cooperative(not throughput_mode)  # throughput mode: several batches in flight (include/blscurve_mi355x.h)
     cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)      # the one blocking caller: latency mode
-    fv_caches = [m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=nthreads, device=local) for _ in range(inflight)] if sharded_path else []
-    lo, hi, first, count = m.shard_plan(n_total, nthreads, world, rank)
-    assert count == n
+    dt = run.timed(a.steps, a.warmup)
+    exchange, stage_acc, gen_s = run.exchange, run.stage_acc, run.gen_s
 
-    exchange = {"mode": a.exchange if backend == "nccl" else "host"}
-    gathered = [torch.zeros(world * 640, dtype=torch.uint8, device=dev) for _ in range(inflight)] if sharded_path else []
-
-    def all_gather_host(blob):
-        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        if backend == "nccl":
-            mine = mine.to(dev)
-        allst = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allst, mine)
-        return [bytes(t.cpu().numpy().tobytes()) for t in allst]
-
-    # every context writes its shard blob straight into a torch tensor: the send buffer of the collective
-    mine_t = [torch.zeros(640, dtype=torch.uint8, device=dev) for _ in range(inflight)] if sharded_path else []
-    for c, t in zip(caches, mine_t):
-        c.set_shard_blob_ptr(t.data_ptr())
-
-    stage_acc = {}
-
-    def record_timings(c):
-        for kk, v in list(c.timings().items()) + list(c.kernel_timings().items()):
-            stage_acc[kk] = stage_acc.get(kk, 0.0) + v
-
-    def submit(slot, after):
-        c, st = caches[slot], streams[slot]
-        if not sharded_path:
-            c.submit_device(d_sets.data_ptr(), n, rnd, st.cuda_stream, after=after)
-        else:
-            c.shard_submit_device(d_sets.data_ptr(), n_total, lo, hi, rnd, st.cuda_stream, after=after)
-
-    fv_busy = [False] * inflight
-
-    def fv_drain(slot):
-        """Verdict of the merge + final exponentiation enqueued for this slot one round ago (rank 0)."""
-        if not fv_busy[slot]:
-            return True
-        fv_busy[slot] = False
-        return fv_caches[slot].finalverify_wait()
-
-    def collect(slot, record):
-        c, st = caches[slot], streams[slot]
-        if not sharded_path:
-            res = c.wait()
-        elif exchange["mode"] == "device":
-            # The shard's blob is in its send buffer (device memory) once shard_wait returns.  The all_gather runs on device
-            # buffers (RCCL over xGMI) and is issued only now: torch enqueues collectives on a stream of its own, and a
-            # collective that had to wait there for a whole batch would block the hardware queue it shares with a caller
-            # stream (measured: 18.3 instead of 13.5 ms per step when the all_gather is enqueued right behind the submit).
-            # Merge + final exponentiation (rank 0) are enqueued behind the collective; their verdict is read one round later
-            # (fv_drain), so the host never waits for them while other batches are in flight.
-            res = fv_drain(slot)
-            state, okf = c.shard_wait()
-            with torch.cuda.stream(st):
-                dist.all_gather_into_tensor(gathered[slot], mine_t[slot])
-            if rank == 0:
-                fv_caches[slot].finalverify_blobs_submit(gathered[slot].data_ptr(), world, 640, st.cuda_stream)
-                fv_busy[slot] = True
-        else:
-            state, okf = c.shard_wait()
-            blobs = all_gather_host(state + bytes([1 if okf else 0]) + bytes(7))
-            res = True
-            if rank == 0:
-                res = all(b[576] == 1 for b in blobs) and fv_caches[slot].finalverify_shards([b[:576] for b in blobs])
-        if record:
-            record_timings(c)
-        return res
-
-    def run_steps(k, record):
-        """One host thread keeps `inflight` batches in flight with the submit / wait entry points (context
-        i % inflight; a context is waited for right before it is reused, i.e. oldest first).  Every batch is
-        chained to the one submitted before it (`after`): it starts when that one has finished hashing and its public-key
-        multiplications, so the batches in flight sit at different stages and a serial tail always runs beside whole-chip
-        kernels of another batch."""
-        ok = True
-        busy = [False] * inflight
-        for it in range(k):
-            slot = it % inflight
-            if busy[slot]:
-                ok = collect(slot, record) and ok
-            # chaining staggers whole-chip batches; small batches do not fill the chip and simply run side by side
-            after = caches[(slot - 1) % inflight] if (inflight > 1 and n >= 32768) else None
-            submit(slot, after)
-            busy[slot] = True
-        for j in range(inflight):
-            slot = (k + j) % inflight
-            if busy[slot]:
-                ok = collect(slot, record) and ok
-                busy[slot] = False
-        for slot in range(inflight):
-            ok = fv_drain(slot) and ok
-        return ok
-
-    def run_steps_threads(k, record):
-        """--threads: one blocking call per host thread (N = 1 only)."""
-        from concurrent.futures import ThreadPoolExecutor
-        import queue
-        free = queue.Queue()
-        for i in range(inflight):
-            free.put(i)
-
-        def one(_):
-            slot = free.get()
-            try:
-                return caches[slot].verify_device(d_sets.data_ptr(), n, rnd, streams[slot].cuda_stream)
-            finally:
-                free.put(slot)
-        with ThreadPoolExecutor(max_workers=inflight) as pool:
-            return all(pool.map(one, range(k)))
-
-    runner = run_steps_threads if (a.threads and not sharded_path) else run_steps
-
-    def sync():
-        if sharded_path:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    try:
-        assert runner(max(a.warmup, 0), False), "warm-up batch must verify"
-    except Exception as e:                      # the device-side exchange cannot be exercised before a multi-GPU node exists
-        if not (sharded_path and exchange["mode"] == "device"):
-            raise
-        exchange["mode"] = "host"
-        exchange["fallback"] = "device-side exchange failed (%s: %s); host exchange used" % (type(e).__name__, str(e)[:200])
-        torch.cuda.synchronize()
-        for i in range(inflight):
-            fv_busy[i] = False
-        for c in caches + fv_caches:
-            try:
-                c.shard_wait()
-            except Exception:
-                pass
-            try:
-                c.finalverify_wait()
-            except Exception:
-                pass
-        assert runner(max(a.warmup, 0), False), "warm-up batch must verify"
-    if sharded_path and world > 1:
-        # every rank must run the same exchange: if any rank fell back to the host exchange, all do
-        flag = torch.tensor([1 if exchange["mode"] == "device" else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and exchange["mode"] == "device":
-            exchange["mode"] = "host"
-            exchange["fallback"] = "another rank fell back to the host exchange"
-            assert runner(max(a.warmup, 0), False), "warm-up batch must verify"
-    sync()
-    t0 = time.perf_counter()
-    ok = runner(a.steps, True)
-    sync()
-    dt = time.perf_counter() - t0
-    assert ok
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if sharded_path:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
+    out = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         all_ms = {k: v / a.steps for k, v in stage_acc.items()}
@@ -295,14 +446,16 @@ def main():
         alone = one["kernel_alone_ms"]
         if not any(k in KERNEL_BYTES for k in alone):              # --threads with --no-one-caller records no stage timers
             alone = {"k_lineprod": ms_per_step}
-        dom = max((k for k in alone if k in KERNEL_BYTES), key=lambda k: alone[k])      # the dominant single kernel, by its un-overlapped duration
-        alg_bytes = KERNEL_BYTES[dom] * n
-        dom_ms = timed_kernel_ms.get(dom, alone[dom])
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         prop = torch.cuda.get_device_properties(dev)
         mad_total = sum(MAD_PER_TUPLE.values())
         mad_peak = prop.multi_processor_count * 4 * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
         mad_achieved = mad_total * n / (ms_per_step * 1e-3)
+        # the dominant kernel = the one with the most multiply-add WORK per batch (the bound of this path), not the longest
+        # un-overlapped duration (which a nearly empty second round of waves can inflate)
+        dom = max((k for k in alone if k in KERNEL_BYTES), key=lambda k: MAD_PER_TUPLE.get(k, 0))
+        alg_bytes = KERNEL_BYTES[dom] * n
+        dom_ms = timed_kernel_ms.get(dom, alone[dom])
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "BLS sig verifications/sec (batch)",
             "value": n_total * a.steps / dt,
@@ -316,7 +469,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic: %d distinct valid (pk, SHA256('msg'+i), sig) tuples per GPU (made by the device signer), "
-                    "rnd=SHA256('Mr F was here'), resident in HBM" % n,
+                    "rnd=SHA256('Mr F was here') re-hashed before every step, resident in HBM" % n,
             "config": {"workload": "BatchedBLSVerifier batchVerify, %d-tuple batch per GPU" % n, "global_batch": n_total,
                        "blinding_chains": nthreads, "parallelism": "shard%d" % world, "batches_in_flight": inflight,
                        "context_mode": "throughput" if throughput_mode else "latency",
@@ -345,7 +498,8 @@ def main():
                                                            "v_mad_u64_u32 issues one per 2.28 ns per SIMD at 4 waves per SIMD (2.41 at 8, 2.87 at 1), "
                                                            "not one per 4 cycles at 2.4 GHz = 1.67 ns"},
                          "note": "the path is integer multiply-add bound, not HBM bound (1.2e4 multiply-adds per input byte): int_mad is the roofline "
-                                 "that says how good the kernels are; the HBM fraction is reported because the contract asks for it"},
+                                 "that says how good the kernels are; the HBM fraction is reported because the contract asks for it.  The dominant kernel "
+                                 "is the one with the most multiply-add work per batch"},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "kernel_ms_timed_region": {k: round(v, 3) for k, v in timed_kernel_ms.items()},
             "kernel_ms_alone": {k: round(v, 3) for k, v in alone.items()},
@@ -358,6 +512,23 @@ def main():
         }
         if not a.no_aux and world == 1 and not a.force_dist:
             out["aux"] = aux_rows(m, cache, dev)
+    # ---- N > 1, outside the timed region: the other multi-GPU rows (every rank takes part)
+    if world > 1 and not a.no_aux:
+        run.close()
+        del run, caches, d_sets
+        torch.cuda.synchronize()
+        multi = {"g1_msm": msm_rows_sharded(m, cache, dev, rank, world, backend, ctl)}
+        if world == 8:
+            # BASELINE config 5: 2^20 tuples across 8 GPUs = 131 072 per GPU
+            run5 = ShardedRun(m, a, dev, local, rank, world, backend, ctl, 131072, True)
+            k5 = max(6, min(a.steps, 20))
+            dt5 = run5.timed(k5, 3)
+            multi["config5_batchVerify_2^20"] = {"verifications_per_s": run5.n_total * k5 / dt5, "ms_per_step": dt5 / k5 * 1e3, "global_batch": run5.n_total,
+                                                 "tuples_per_gpu": 131072, "steps": k5, "exchange": run5.exchange}
+            run5.close()
+        if rank == 0:
+            out["multi_gpu"] = multi
+    if rank == 0:
         if not a.no_cpu and world == 1 and not a.force_dist:                # the CPU baseline is timed at N = 1 only
             import c_oracle as co      # the CPU restatement: this leg only
             out["cpu_baseline"] = cpu_baseline(co, a.cpu_sample, rnd)
@@ -707,16 +878,19 @@ def cpu_baseline(co, sample, rnd):
     """The C restatement of the reference algorithm (one pairing context per thread, parallel_chunks
     split, update loop, commit, merge, finalverify) on the host cores, the whole leg bounded to roughly 30 s."""
     cores, aff, quota = host_cores()
-    probe = co.make_batch(max(8 * cores, 64), seed=1 << 40)
-    # 1 -> N thread scaling at 8 tuples per thread (tells a real core count from an oversubscribed one)
+    probe = co.make_batch(max(16 * cores, 64), seed=1 << 40)
+    co.set_num_threads(1)
+    assert co.batch_verify(probe[:320 * 8], rnd, 1)          # warm-up: the first call pays for loading the library and its tables
+    # 1 -> N thread scaling on >= 64 tuples (16 per thread: two full N_MAX = 8 Miller batches each), which tells a real core
+    # count from an oversubscribed one
     scaling = []
     t = 1
     while True:
         co.set_num_threads(t)
-        k = 8 * t
+        k = max(64, 16 * t)
         t0 = time.perf_counter()
         assert co.batch_verify(probe[:320 * k], rnd, t)
-        scaling.append({"threads": t, "verifications_per_s": round(k / (time.perf_counter() - t0), 1)})
+        scaling.append({"threads": t, "tuples": k, "verifications_per_s": round(k / (time.perf_counter() - t0), 1)})
         if t >= cores:
             break
         t = min(cores, t * 2)

@@ -33,14 +33,19 @@ extern "C" {
 #define MI355_BLS_BLOB_BYTES 640     /* device-resident shard blob: 576-byte state | u32 ok word | zero padding */
 
 #define MI355_BLS_ERR_HIP (-1)       /* a HIP call failed; see mi355_bls_last_error() */
-#define MI355_BLS_ERR_CAPACITY (-2)  /* n exceeds the context's capacity */
+#define MI355_BLS_ERR_CAPACITY (-2)  /* n exceeds the context's capacity (never returned by the batchVerify / aggregateVerify entry points:
+                                        they process larger inputs in slices) */
 #define MI355_BLS_ERR_ARG (-3)
 
 typedef struct mi355_bls_ctx mi355_bls_ctx;
 
 /* BatchedBLSVerifierCache.init / init(tp) (bls_batch_verifier.nim:108-119): persistent device
- * workspace sized for batches of up to max_sets triplets on HIP device `device`.  One context per
- * concurrent caller, reusable across calls (bls_batch_verifier.nim:389-391). */
+ * workspace on HIP device `device`.  One context per concurrent caller, reusable across calls
+ * (bls_batch_verifier.nim:389-391).  max_sets sizes the workspace (about 29 KB of HBM per set), it does NOT bound
+ * input.len: like the reference's cache (per-thread contexts only, :108-119,:141) every batchVerify entry point accepts
+ * any n - a batch (or shard) larger than max_sets is processed in ceil(n / max_sets) balanced slices on the same stream,
+ * whose committed states are merged on the device (blst_pairing_merge semantics).  Size it for the batches you expect:
+ * a slice that fills the chip (>= 65 536 sets) runs at full throughput. */
 int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets);
 void mi355_bls_ctx_destroy(mi355_bls_ctx* ctx);
 const char* mi355_bls_last_error(void);
@@ -107,10 +112,14 @@ int mi355_bls_finalverify_shards(mi355_bls_ctx* ctx, const uint8_t* fp12s, size_
 
 /* Device-resident exchange for one-process-per-GPU callers (the multi-GPU bench): every shard submit also writes the shard's
  * state + ok word into the context's blob buffer (MI355_BLS_BLOB_BYTES, device memory) on the submit's stream.  The caller
- * gathers the blobs of all ranks with a collective on device buffers (RCCL all_gather, enqueued behind the submit on the same
- * stream) and hands the gathered buffer to finalverify_blobs: merge (blst_pairing_merge, core :657-666) + finalVerify
- * (:670-672) on k blobs `stride_bytes` apart in DEVICE memory, enqueued on `stream`; finalverify_wait blocks and returns the
- * verdict (1 only if every shard's ok word is 1 and the product is one).  No host round trip between submit and verdict. */
+ * gathers the blobs of all ranks with a collective on device buffers (RCCL all_gather) and hands the gathered buffer to
+ * finalverify_blobs: merge (blst_pairing_merge, core :657-666) + finalVerify (:670-672) on k blobs `stride_bytes` apart in
+ * DEVICE memory, enqueued on `stream`; finalverify_wait blocks and returns the verdict (1 only if every shard's ok word is 1
+ * and the product is one).  Nothing but the verdict word crosses PCIe.  (The collective may be enqueued right behind the
+ * submit on the same stream; the bench waits for the shard first - mi355_bls_batch_shard_wait, a host synchronisation - because
+ * torch issues collectives on a stream of its own, where one that waits for a whole batch blocks a hardware queue.)
+ * finalverify_blobs keeps its verdict word and GT value apart from the batch path's, so a context may take its next shard
+ * while a merge submitted on it is still in flight on another stream. */
 int mi355_bls_ctx_shard_blob_device(mi355_bls_ctx* ctx, void** d_blob);
 /* Redirect the blob to the caller's own device buffer (MI355_BLS_BLOB_BYTES, 16-byte aligned; e.g. the send buffer of the
  * collective, so no copy is needed); NULL restores the context's internal buffer. */
@@ -124,11 +133,14 @@ int mi355_bls_shard_plan(size_t n_total, uint32_t num_threads, uint32_t world, u
                          size_t* first, size_t* count);
 
 /* batchVerifyParallel across several GPUs of one node from ONE host thread (bls_batch_verifier.nim:296-371 with devices in
- * place of taskpool threads): ctxs[g] is a context on device g (all with the same num_threads, each with capacity for its
- * shard, ceil(n / ngpu) + 1 sets is enough); shard g = the chunk block mi355_bls_shard_plan gives rank g.  All shards are
- * enqueued asynchronously (:342-357), their 576-byte states return through pinned host memory, ctxs[0] merges them and runs
- * the one final exponentiation (:360-371).  `sets`: n x 320 B in host memory; the _device form takes d_sets[g] = shard g's
- * records already resident on device g.  n == 0 -> 0. */
+ * place of taskpool threads): ctxs[g] is a context on device g (all with the same num_threads; a shard larger than its
+ * context's capacity is sliced, the largest shard is mi355_bls_shard_plan(...).count of rank 0); shard g = the chunk block
+ * mi355_bls_shard_plan gives rank g.  The plan and every context are validated before anything is enqueued; the caller's
+ * host range is page-locked for the call so that all shards' copies and kernels are enqueued asynchronously (:342-357) and
+ * device g does not wait for device g - 1's staging; the 576-byte states return through pinned host memory, ctxs[0] merges
+ * them and runs the one final exponentiation (:360-371).  If enqueuing a shard fails, the shards already submitted are waited
+ * for before the error is returned, so every context stays usable.  `sets`: n x 320 B in host memory; the _device form takes
+ * d_sets[g] = shard g's records already resident on device g.  n == 0 -> 0. */
 int mi355_bls_batch_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* sets, size_t n, const uint8_t rnd[32]);
 int mi355_bls_batch_verify_multi_device(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* const d_sets[], size_t n, const uint8_t rnd[32]);
 
@@ -191,6 +203,29 @@ int mi355_bls_p2s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p2[288],
 int mi355_bls_p1s_mult_pippenger_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_points, size_t npoints,
                                         const void* d_scalars, size_t nbits, void* stream);
 
+/* Point-sharded MSM across the GPUs of one node (blst_p1s_mult_pippenger, blst_abi.nim:336-340, over devices; the bench shape
+ * benchmarks/bls12381_msm_g1.nim:47-59): device g computes the full-width partial sum of points [first_g, first_g + count_g)
+ * (mi355_bls_msm_shard_range: balanced contiguous blocks), the 144-byte partials are added (blst_p1_add_or_double,
+ * blst_abi.nim:278).
+ *   _multi         one host thread, ctxs[g] on device g, host arrays as mi355_bls_p1s_mult_pippenger (32-byte scalar images);
+ *                  all shards are enqueued before any is waited for, ctxs[0] adds the partials
+ *   _multi_device  d_points[g] / d_scalars[g] = shard g's arrays already resident on device g
+ *   _partial_device + p1s_add(_device)   one process per GPU: every rank leaves its partial in device memory (the send buffer
+ *                  of an RCCL all_gather), rank 0 adds the gathered partials (k x stride_bytes in device memory, or k x 144 B in
+ *                  host memory) */
+void mi355_bls_msm_shard_range(size_t npoints, uint32_t world, uint32_t rank, size_t* first, size_t* count);
+int mi355_bls_p1s_mult_pippenger_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p1[144], const void* const points[], size_t npoints,
+                                       const uint8_t* const scalars[], size_t nbits);
+int mi355_bls_p2s_mult_pippenger_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p2[288], const void* const points[], size_t npoints,
+                                       const uint8_t* const scalars[], size_t nbits);
+int mi355_bls_p1s_mult_pippenger_multi_device(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p1[144], const void* const d_points[], size_t npoints,
+                                              const void* const d_scalars[], size_t nbits);
+int mi355_bls_p1s_mult_pippenger_partial_device(mi355_bls_ctx* ctx, void* d_out_p1, const void* d_points, size_t npoints, const void* d_scalars,
+                                                size_t nbits, void* stream);
+int mi355_bls_p1s_add(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const uint8_t* parts, size_t k);
+int mi355_bls_p2s_add(mi355_bls_ctx* ctx, uint8_t ret_p2[288], const uint8_t* parts, size_t k);
+int mi355_bls_p1s_add_device(mi355_bls_ctx* ctx, uint8_t ret_p1[144], const void* d_parts, size_t k, size_t stride_bytes, void* stream);
+
 /* Batched PublicKey.fromBytes / Signature.fromBytes (blscurve/blst/bls_sig_io.nim:42-58, 81-99) on the device:
  * n compressed public keys (48 B each), 32-byte messages and compressed signatures (96 B each), ZCash format.
  * Per tuple: blst_p1_uncompress, "public key is not infinity", blst_p1_affine_in_g1, blst_p2_uncompress,
@@ -242,9 +277,20 @@ int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks
  * blst_min_pubkey_sig_core.nim:305-414): e(G1, sig) == prod_i e(pk_i, H(m_i)) for n (public key, message) pairs
  * with messages of arbitrary length: message i = msgs[msg_offsets[i] .. msg_offsets[i+1]) (n + 1 offsets).
  * pks: n x 96 B, sig: 192 B, host memory.  n == 0 -> 0; infinity public key -> 0.  The proofs of possession
- * must have been checked by the caller, as for the reference's two-argument overloads. */
+ * must have been checked by the caller, as for the reference's two-argument overloads.  Any n: inputs beyond the
+ * context's capacity are processed in slices. */
 int mi355_bls_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n,
                                const void* sig);
+
+/* The streaming form, ContextCoreAggregateVerify.init / update / finish (blst_min_pubkey_sig_core.nim:321-414; driven by
+ * bls_sig_min_pubkey.nim:127-199 for the AoS and SoA overloads): init resets the context's pair list; update(publicKey,
+ * message) appends one pair and returns 1, or 0 for the infinity public key (the reference's update returns false:
+ * BLST_PK_IS_INFINITY) after which finish returns 0; finish(signature) = commit + finalVerify: one device call over the
+ * collected pairs, returns the verdict (0 when no pair was added) and consumes the context (init again before reuse).
+ * pk: 96-byte blst_p1_affine, sig: 192-byte blst_p2_affine, any message length. */
+int mi355_bls_aggv_init(mi355_bls_ctx* ctx);
+int mi355_bls_aggv_update(mi355_bls_ctx* ctx, const void* pk, const uint8_t* msg, size_t msg_len);
+int mi355_bls_aggv_finish(mi355_bls_ctx* ctx, const void* sig);
 
 /* Batch signer / input generator.  Per tuple i, from a 32-byte little-endian secret scalar
  * (blst_scalar image, SecretKey, blst_min_pubkey_sig_core.nim:43-66) and a 32-byte message:
@@ -273,6 +319,13 @@ int mi355_bls_last_timings(mi355_bls_ctx* ctx, float out[8]);
 /* Per-kernel split of the two-kernel stages of the last batch call (ms): k_hash_map, k_hash_clear (hash_to_g2),
  * k_lineprod, k_lineprod2 (line_products). */
 int mi355_bls_last_kernel_timings(mi355_bls_ctx* ctx, float out[4]);
+
+/* Test hooks (no reference counterpart).  debug_fail_next_enqueue: the next batch / shard enqueue on this context fails with
+ * MI355_BLS_ERR_HIP before touching the device (exercises the multi-device driver's clean-up path).  debug_multi_enqueue_us:
+ * host time in microseconds, counted from the start of the last mi355_bls_batch_verify_multi* call of this thread, at which each
+ * device's shard was handed to its stream (the start skew between devices); returns the number of devices recorded. */
+int mi355_bls_debug_fail_next_enqueue(mi355_bls_ctx* ctx);
+size_t mi355_bls_debug_multi_enqueue_us(float* out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,21 @@ def lib():
         L.mi355_bls_sign_sets.argtypes = [vp, cp, cp, sz, vp, vp]
         L.mi355_bls_sign_sets_device.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.mi355_bls_aggregate_verify.argtypes = [vp, cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
+        L.mi355_bls_aggv_init.argtypes = [vp]
+        L.mi355_bls_aggv_update.argtypes = [vp, cp, cp, sz]
+        L.mi355_bls_aggv_finish.argtypes = [vp, cp]
+        L.mi355_bls_msm_shard_range.argtypes = [sz, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.mi355_bls_msm_shard_range.restype = None
+        L.mi355_bls_p1s_mult_pippenger_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
+        L.mi355_bls_p2s_mult_pippenger_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
+        L.mi355_bls_p1s_mult_pippenger_multi_device.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
+        L.mi355_bls_p1s_mult_pippenger_partial_device.argtypes = [vp, vp, vp, sz, vp, sz, vp]
+        L.mi355_bls_p1s_add.argtypes = [vp, ctypes.c_char_p, cp, sz]
+        L.mi355_bls_p2s_add.argtypes = [vp, ctypes.c_char_p, cp, sz]
+        L.mi355_bls_p1s_add_device.argtypes = [vp, ctypes.c_char_p, vp, sz, sz, vp]
+        L.mi355_bls_debug_fail_next_enqueue.argtypes = [vp]
+        L.mi355_bls_debug_multi_enqueue_us.argtypes = [ctypes.POINTER(ctypes.c_float), sz]
+        L.mi355_bls_debug_multi_enqueue_us.restype = sz
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]
         L.mi355_bls_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.mi355_bls_last_kernel_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -515,3 +530,93 @@ def aggregateVerify(cache, publicKeys, messages, signature):
         offs.append(offs[-1] + len(x))
     arr = (ctypes.c_uint32 * len(offs))(*offs)
     return bool(_check(lib().mi355_bls_aggregate_verify(cache._h, b"".join(pks), b"".join(msgs) or b"\0", arr, len(pks), bytes(signature))))
+
+
+class ContextCoreAggregateVerify:
+    """blst_min_pubkey_sig_core.nim:305-414, the streaming form of aggregateVerify: init() / update(publicKey, message) -> bool /
+    finish(signature) -> bool, on a BatchedBLSVerifierCache's device context (mi355_bls_aggv_*)."""
+
+    def __init__(self, cache):
+        self._c = cache
+
+    def init(self):
+        _check(lib().mi355_bls_aggv_init(self._c._h))
+
+    def update(self, publicKey, message):
+        if len(publicKey) != 96:
+            raise ValueError("public keys are 96-byte blst_p1_affine images")
+        m = bytes(message)
+        return bool(_check(lib().mi355_bls_aggv_update(self._c._h, bytes(publicKey), m or None, len(m))))
+
+    def finish(self, signature):
+        if len(signature) != 192:
+            raise ValueError("the signature is a 192-byte blst_p2_affine image")
+        return bool(_check(lib().mi355_bls_aggv_finish(self._c._h, bytes(signature))))
+
+
+def aggregateVerifyStreaming(cache, publicKeys, messages, signature):
+    """aggregateVerify written as the reference writes it (bls_sig_min_pubkey.nim:153-174): ctx.init, one update per pair, finish."""
+    pks, msgs = list(publicKeys), list(messages)
+    if len(pks) != len(msgs) or len(pks) == 0:
+        return False
+    ctx = ContextCoreAggregateVerify(cache)
+    ctx.init()
+    for pk, m in zip(pks, msgs):
+        if not ctx.update(pk, m):
+            return False
+    return ctx.finish(signature)
+
+
+def msm_shard_range(npoints, world, rank):
+    first, count = ctypes.c_size_t(), ctypes.c_size_t()
+    lib().mi355_bls_msm_shard_range(npoints, world, rank, ctypes.byref(first), ctypes.byref(count))
+    return first.value, count.value
+
+
+def p1s_mult_pippenger_multi(caches, points, scalars, nbits=255, g2=False):
+    """blst_p1s_mult_pippenger (g2: blst_p2s) point-sharded over several devices from one host thread: caches[g] lives on device g."""
+    ab = 192 if g2 else 96
+    if len(points) % ab or len(scalars) % 32 or len(points) // ab != len(scalars) // 32:
+        raise ValueError("points: n x %d bytes, scalars: n x 32 bytes" % ab)
+    n = len(points) // ab
+    arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
+    pb = ctypes.create_string_buffer(bytes(points), len(points)) if n else None
+    sb = ctypes.create_string_buffer(bytes(scalars), len(scalars)) if n else None
+    pl = (ctypes.c_void_p * 2)(ctypes.addressof(pb) if n else None, None)
+    sl = (ctypes.c_void_p * 2)(ctypes.addressof(sb) if n else None, None)
+    out = ctypes.create_string_buffer(288 if g2 else 144)
+    fn = lib().mi355_bls_p2s_mult_pippenger_multi if g2 else lib().mi355_bls_p1s_mult_pippenger_multi
+    _check(fn(arr, len(caches), out, pl, n, sl, nbits))
+    return out.raw
+
+
+def p1s_mult_pippenger_multi_device(caches, d_points, n, d_scalars, nbits=255):
+    """Same with shard g's arrays (msm_shard_range(n, len(caches), g)) already resident on device g: d_points[g], d_scalars[g]."""
+    arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
+    dp = (ctypes.c_void_p * len(caches))(*d_points)
+    ds = (ctypes.c_void_p * len(caches))(*d_scalars)
+    out = ctypes.create_string_buffer(144)
+    _check(lib().mi355_bls_p1s_mult_pippenger_multi_device(arr, len(caches), out, dp, n, ds, nbits))
+    return out.raw
+
+
+def p1s_mult_pippenger_partial_device(cache, d_out, d_points, n, d_scalars, nbits=255, stream=0):
+    """This device's partial of a point-sharded MSM, left at d_out (144 B, device memory) behind the rest of `stream`."""
+    _check(lib().mi355_bls_p1s_mult_pippenger_partial_device(cache._h, d_out, d_points, n, d_scalars, nbits, stream))
+
+
+def p1s_add(cache, parts, g2=False):
+    """Sum of k blst_p1 (g2: blst_p2) Jacobian images (blst_p1_add_or_double, blst_abi.nim:278): the merge of MSM partials."""
+    jb = 288 if g2 else 144
+    buf = bytes(parts) if isinstance(parts, (bytes, bytearray, memoryview)) else b"".join(parts)
+    if len(buf) % jb or not buf:
+        raise ValueError("k x %d-byte Jacobian images" % jb)
+    out = ctypes.create_string_buffer(jb)
+    _check((lib().mi355_bls_p2s_add if g2 else lib().mi355_bls_p1s_add)(cache._h, out, buf, len(buf) // jb))
+    return out.raw
+
+
+def p1s_add_device(cache, d_parts, k, stride=144, stream=0):
+    out = ctypes.create_string_buffer(144)
+    _check(lib().mi355_bls_p1s_add_device(cache._h, out, d_parts, k, stride, stream))
+    return out.raw

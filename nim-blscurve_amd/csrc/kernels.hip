@@ -18,6 +18,7 @@
 // loads/stores of one limb group are contiguous across the wave (coalesced dwordx4).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -163,6 +164,9 @@ __device__ __forceinline__ g2_aff ld_g2a_blst(const uint32_t* w) {
     return g2_aff{fp2{ld_fp_blst(w), ld_fp_blst(w + 12)}, fp2{ld_fp_blst(w + 24), ld_fp_blst(w + 36)}};
 }
 __device__ __forceinline__ g1_jac ld_g1_blst(const uint32_t* w) { return g1_jac{ld_fp_blst(w), ld_fp_blst(w + 12), ld_fp_blst(w + 24)}; }
+__device__ __forceinline__ g2_jac ld_g2_blst(const uint32_t* w) {
+    return g2_jac{fp2{ld_fp_blst(w), ld_fp_blst(w + 12)}, fp2{ld_fp_blst(w + 24), ld_fp_blst(w + 36)}, fp2{ld_fp_blst(w + 48), ld_fp_blst(w + 60)}};
+}
 __device__ __forceinline__ void st_g1_blst(uint32_t* w, const g1_jac& a) {
     st_fp_blst(w, a.x); st_fp_blst(w + 12, a.y); st_fp_blst(w + 24, a.z);
 }
@@ -209,7 +213,12 @@ __device__ __forceinline__ fp fp_from_role(const fp& a, uint32_t gbase, uint32_t
 // Tuples are addressed relative to tuple_base (first tuple of this shard).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd, uint64_t n_total, uint32_t nchunks, uint32_t chunk_lo,
-                                                uint32_t chunk_cnt, uint64_t tuple_base, uint64_t* __restrict__ r_out) {
+                                                uint32_t chunk_cnt, uint64_t tuple_base, uint64_t tuple_cnt, const uint32_t* __restrict__ carry_in,
+                                                uint32_t* __restrict__ carry_out, uint64_t* __restrict__ r_out) {
+    // Only the links of tuples [tuple_base, tuple_base + tuple_cnt) are written (a SLICE of the shard: a batch larger than the
+    // context's capacity is processed slice by slice).  A chunk that the previous slice cut in two resumes from the chain state
+    // that slice left in carry_in (8 seed words); a chunk this slice cuts leaves its state in carry_out (a different buffer: the
+    // two may belong to different lanes of this launch).  Slices are processed in order, so at most one chunk is open at a time.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunk_cnt) return;
     uint64_t c = (uint64_t)chunk_lo + t;
@@ -222,13 +231,20 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
         off = base * c + rem;
         len = base;
     }
-    sha256_ctx ctx;
-    sha256_begin(ctx);
-    for (int i = 0; i < 32; i++) sha256_put(ctx, rnd[i]);
-    for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
+    const uint64_t t_hi = tuple_base + tuple_cnt;
+    uint64_t j0 = off < tuple_base ? tuple_base - off : 0, j1 = off + len > t_hi ? t_hi - off : len;
     uint32_t seed[8];
-    sha256_end(ctx, seed);
-    for (uint64_t j = 0; j < len; j++) {
+    if (j0 > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) seed[i] = carry_in[i];
+    } else {
+        sha256_ctx ctx;
+        sha256_begin(ctx);
+        for (int i = 0; i < 32; i++) sha256_put(ctx, rnd[i]);
+        for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
+        sha256_end(ctx, seed);
+    }
+    for (uint64_t j = j0; j < j1; j++) {
         uint64_t r;
         do {
             uint32_t nx[8];
@@ -238,6 +254,10 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
             r = digest_low_u64_le(seed);
         } while (r == 0);
         r_out[off + j - tuple_base] = r;
+    }
+    if (j1 < len) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) carry_out[i] = seed[i];
     }
 }
 
@@ -600,7 +620,8 @@ __device__ __forceinline__ void c12_frob2(c12_lds& S, int d, int a) {
     if (lane < 6) S.r[d][lane] = fp2_mul_fp(S.r[a][lane], S.frob2[lane]);
     __syncthreads();
 }
-__device__ __forceinline__ void c12_load(c12_lds& S, int d, const uint32_t* g) {   // blst_fp12 image (576 B)
+template <class LDS>
+__device__ __forceinline__ void c12_load(LDS& S, int d, const uint32_t* g) {   // blst_fp12 image (576 B)
     int lane = threadIdx.x;
     if (lane < 6) S.r[d][c12_flat_of_tower(lane)] = fp2{ld_fp_blst(g + 24 * lane), ld_fp_blst(g + 24 * lane + 12)};
     __syncthreads();
@@ -618,7 +639,8 @@ __device__ __forceinline__ void c12_load_step(c12_lds& S, int d, int s) {
     }
     __syncthreads();
 }
-__device__ __forceinline__ void c12_store(const c12_lds& S, int a, uint32_t* g) {
+template <class LDS>
+__device__ __forceinline__ void c12_store(const LDS& S, int a, uint32_t* g) {
     int lane = threadIdx.x;
     if (lane < 6) {
         const fp2& v = S.r[a][c12_flat_of_tower(lane)];
@@ -672,6 +694,19 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_fold(const uint32_t* __restric
         c12_mul(S, 0, 0, 1);
     }
     c12_store_int(S, 0, dst + ((size_t)s * nb + b) * F12W);
+}
+
+// Committed pairing states (blst_fp12 images, 144 words each) on the engine: states[dst] = states[a] * states[b], or a copy of
+// states[a] when b < 0.  blst_pairing_merge (blst_abi.nim:508) between the slices of a batch that is larger than the context's
+// capacity: every slice commits its own state, the running product lives in slot 1.
+__global__ void __launch_bounds__(TAIL_THREADS) k_state_mul(uint32_t* __restrict__ states, int dst, int a, int b) {
+    __shared__ fold_lds S;
+    c12_load(S, 0, states + (size_t)a * 144);
+    if (b >= 0) {
+        c12_load(S, 1, states + (size_t)b * 144);
+        c12_mul(S, 0, 0, 1);
+    }
+    c12_store(S, 0, states + (size_t)dst * 144);
 }
 
 // d = a^x (x < 0, a cyclotomic): square-and-multiply over |x|, then conjugate.  tmp != a.
@@ -1247,6 +1282,22 @@ __global__ void __launch_bounds__(WAVE) k_pip_final(const uint32_t* __restrict__
     if (threadIdx.x == 0) st_jac_blst(out, acc);
 }
 
+// sum of k Jacobian blst images `stride` words apart -> blst image: the merge of the per-device partials of a point-sharded MSM
+__device__ __forceinline__ g1_jac ld_jac_blst(const uint32_t* w, const g1_jac*) { return ld_g1_blst(w); }
+__device__ __forceinline__ g2_jac ld_jac_blst(const uint32_t* w, const g2_jac*) { return ld_g2_blst(w); }
+template <class F>
+__global__ void __launch_bounds__(WAVE) k_jac_sum_blst(const uint32_t* __restrict__ parts, uint32_t k, uint32_t stride, uint32_t* __restrict__ out) {
+    jac<F> acc = jac_inf<F>();
+    for (uint32_t j = threadIdx.x; j < k; j += WAVE) acc = padd(acc, ld_jac_blst(parts + (size_t)j * stride, (const jac<F>*)nullptr));
+    int top = 32;
+    while (top >= 1 && (uint32_t)top >= k) top >>= 1;
+    for (int d = top; d >= 1; d >>= 1) {
+        jac<F> o = shfl_down_struct(acc, d);
+        acc = padd(acc, o);
+    }
+    if (threadIdx.x == 0) st_jac_blst(out, acc);
+}
+
 // ------------------------------------------------------------------------------------------
 // Signature side of large batches: bucket fold + bilinearity instead of n 64-bit scalar multiplications.
 //   e(-G1, sum_i [r_i]S_i) = prod_{w,d} e(-[d 2^(cw)]G1, B_{w,d}),   B_{w,d} = sum of the S_i whose w-th c-bit
@@ -1394,14 +1445,14 @@ __global__ void __launch_bounds__(WAVE) k_aggv_records(const uint8_t* __restrict
     for (int j = 0; j < 32; j++) recs[(size_t)i * 320 + 96 + j] = msgs[(size_t)i * 32 + j];
 }
 // pairs 0..n-1: P = pk_i (affine, Z = 1); pair n: (P, Q) = (-G1, sig)
-__global__ void __launch_bounds__(WAVE) k_aggv_setup(const uint8_t* __restrict__ pks, uint32_t n, const uint32_t* __restrict__ sig, uint4* __restrict__ H,
+__global__ void __launch_bounds__(WAVE) k_aggv_setup(const uint8_t* __restrict__ pks, uint32_t n, int with_sig, const uint32_t* __restrict__ sig, uint4* __restrict__ H,
                                                      uint4* __restrict__ P, size_t stride, uint32_t* __restrict__ flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         g1_aff pk = ld_g1a_blst(reinterpret_cast<const uint32_t*>(pks + (size_t)i * 96));
         if (aff_is_inf(pk)) atomicOr(flags, 1u);                // BLST_PK_IS_INFINITY -> update() false
         soa_st_g1(P, stride, i, jac_from_aff(pk));
-    } else if (i == n) {
+    } else if (i == n && with_sig) {
         soa_st_g1(P, stride, n, g1_jac{fp_from_const(k::G1_X), fp_from_const(k::G1_NEG_Y), fp_one()});
         soa_st_g2(H, stride, n, jac_from_aff(ld_g2a_blst(sig)));
     }
@@ -1538,7 +1589,12 @@ struct mi355_bls_ctx {
     uint32_t* d_blob_out = nullptr;  // where shard submits write the blob: d_blob, or a caller's device buffer (set_shard_blob_device)
     bool fv_pending = false;         // a finalverify_blobs submit has not been waited for
     hipStream_t fv_stream = nullptr;
-    uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict
+    uint32_t* d_flags = nullptr;     // [0] = update-failed flag, [1] = verdict, [2] = some tuple failed to deserialise / sign, [3] = verdict of finalverify_blobs
+                                     // (a word and a GT buffer of its own: a blob merge may be in flight on another stream while this context takes the next shard)
+    uint32_t* d_gt_fv = nullptr;     // GT of the last finalverify_blobs
+    bool gt_is_fv = false;           // fetch_stage(4): the last GT came from finalverify_blobs
+    uint32_t* d_carry = nullptr;     // 2 x 8 seed words: blinding-chain state of the chunk that a slice boundary cuts (capacity-free batches)
+    bool fail_next_enqueue = false;  // test hook (mi355_bls_debug_fail_next_enqueue)
     uint32_t* h_flags = nullptr;     // pinned host copy of d_flags[0..1] (asynchronous submit / wait)
     bool pending = false;            // a submitted batch has not been waited for yet
     bool coop = true;                // small batches: lane-cooperative kernels (latency) instead of one lane per item (throughput)
@@ -1557,6 +1613,9 @@ struct mi355_bls_ctx {
     xmd32_consts xmd;                // message-independent SHA-256 words of expand_message_xmd for this DST
     std::vector<uint64_t> h_r;       // host-computed scalar chains (serial blinding chain, combine)
     msm_ws* msm = nullptr;           // lazily sized MSM workspace
+    std::vector<uint8_t> av_pks, av_msgs;      // streaming aggregateVerify (mi355_bls_aggv_*): the pairs collected so far
+    std::vector<uint32_t> av_offs;
+    bool av_failed = false;
     msm_ws* msm2 = nullptr;          // a second one: combine runs its G1 and its G2 Pippenger side by side
 };
 
@@ -1570,7 +1629,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_blob, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_gt_fv, c->d_carry, c->d_blob, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -1636,6 +1695,8 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_L, (size_t)N_LINES * F12W * 4);
     ALLOC(c->d_states, 64 * 576);
     ALLOC(c->d_gt, 576);
+    ALLOC(c->d_gt_fv, 576);
+    ALLOC(c->d_carry, 64);
     ALLOC(c->d_blob, MI355_BLS_BLOB_BYTES);
     c->d_blob_out = c->d_blob;
     ALLOC(c->d_flags, 16);
@@ -1797,27 +1858,22 @@ static int enqueue_line_products(mi355_bls_ctx* c, uint32_t npairs, hipStream_t 
     return 0;
 }
 
-// Enqueues everything up to the shard's committed state (d_states slot 0).  n = local tuple count.
+// Enqueues everything up to the committed state (d_states slot 0) of ONE SLICE of a shard: tuples [tuple_base, tuple_base + n) of the
+// global batch, n <= capacity, records at d_sets (device memory).  chunk_lo / chunk_cnt: the blinding chains that overlap the slice.
 // The three producers of Miller pairs are independent until the lines: hashing (k_hash_map, k_hash_clear), [r]PK (k_pkmul) and
 // the signature side (bucket fold).  A batch that fills the chip runs them one after the other on the caller's stream (each is a
 // whole-chip kernel).  A small batch in latency mode runs the last two on the context's side stream beside the hashing: they
 // are all latency-bound there (a few waves each), so this takes about a millisecond off the call.
-static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
-                     size_t tuple_base, size_t n, int serial, const uint8_t rnd[32], hipStream_t st) {
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
-    HIPCHK(hipSetDevice(c->device));
-    std::memcpy(c->h_flags + 4, rnd, 32);                      // pinned staging: the copy below is then truly asynchronous
-    HIPCHK(hipMemcpyAsync(c->d_rnd, c->h_flags + 4, 32, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
+                     size_t tuple_base, size_t n, int serial, size_t serial_off, uint32_t slice, hipStream_t st) {
     uint32_t n32 = (uint32_t)n;
     uint32_t nb = (n32 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
     if (serial) {
-        c->h_r.resize(n);
-        host_serial_chain(rnd, n, c->h_r.data());
-        HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data() + serial_off, n * 8, hipMemcpyHostToDevice, st));
     } else {
-        k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, c->d_r);
+        k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, n, c->d_carry + 8 * (slice & 1),
+                                                                c->d_carry + 8 * ((slice + 1) & 1), c->d_r);
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
     const bool fork = c->coop && c->side && n32 <= 16 * c->slots;       // pk + signature side beside the hashing
@@ -1887,6 +1943,56 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     HIPCHK(hipGetLastError());
     c->last_n = n;
     c->have_gt = false;
+    c->gt_is_fv = false;
+    return 0;
+}
+
+// chunk of the parallel_chunks partition (parallel_chunks.nim:42-66) that tuple t of n_total falls into, B chunks
+static inline uint32_t chunk_of_tuple(size_t n_total, uint32_t B, size_t t) {
+    size_t base = n_total / B, rem = n_total % B, cut = (base + 1) * rem;
+    return (uint32_t)(t < cut ? t / (base + 1) : rem + (t - cut) / base);
+}
+
+// A shard = chunks [chunk_lo, chunk_lo + chunk_cnt) = tuples [tuple_base, tuple_base + n) of the global batch -> committed state in
+// d_states slot 0.  The reference's cache holds per-thread pairing contexts only and accepts any input.len
+// (bls_batch_verifier.nim:108-119,141); here the workspace is sized for `cap` tuples, so a larger shard is processed in
+// ceil(n / cap) balanced SLICES on the same stream: every slice commits its own state (its own signature-side pairs folded in),
+// the running product is kept in slot 1 (blst_pairing_merge, blst_abi.nim:508), the blinding chain of a chunk that a slice
+// boundary cuts is carried over (k_blind).  src_dev: the shard's records in device memory, or src_host: in host memory
+// (staged slice by slice through d_sets).  After a sliced call fetch_stage(0..3) shows the LAST slice.
+static int run_shard(mi355_bls_ctx* c, const uint8_t* src_dev, const uint8_t* src_host, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
+                     size_t tuple_base, size_t n, int serial, const uint8_t rnd[32], hipStream_t st) {
+    (void)chunk_lo; (void)chunk_cnt;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->fail_next_enqueue) {                                 // test hook: an enqueue failure after earlier shards of a multi-device call went out
+        c->fail_next_enqueue = false;
+        g_err = "injected enqueue failure (mi355_bls_debug_fail_next_enqueue)";
+        return MI355_BLS_ERR_HIP;
+    }
+    std::memcpy(c->h_flags + 4, rnd, 32);                      // pinned staging: the copy below is then truly asynchronous
+    HIPCHK(hipMemcpyAsync(c->d_rnd, c->h_flags + 4, 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
+    if (serial) {
+        c->h_r.resize(n);
+        host_serial_chain(rnd, n, c->h_r.data());
+    }
+    const size_t nslices = (n + c->cap - 1) / c->cap;
+    size_t done = 0;
+    for (uint32_t slice = 0; done < n; slice++) {
+        size_t left = nslices - slice, cnt = (n - done + left - 1) / left;          // balanced: never a sliver at the end
+        size_t t0 = tuple_base + done;
+        uint32_t c_lo = serial ? 0 : chunk_of_tuple(n_total, nchunks, t0), c_hi = serial ? 1 : chunk_of_tuple(n_total, nchunks, t0 + cnt - 1) + 1;
+        const uint8_t* d = src_dev ? src_dev + 320 * done : c->d_sets;
+        if (!src_dev) HIPCHK(hipMemcpyAsync(c->d_sets, src_host + 320 * done, cnt * 320, hipMemcpyHostToDevice, st));
+        int rc = run_slice(c, d, n_total, nchunks, c_lo, c_hi - c_lo, t0, cnt, serial, done, slice, st);
+        if (rc) return rc;
+        if (nslices > 1) k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 1, slice ? 1 : 0, slice ? 0 : -1);
+        done += cnt;
+    }
+    if (nslices > 1) {
+        k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 0, 1, -1);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1908,15 +2014,15 @@ static int collect_timings(mi355_bls_ctx* c, int last_ev) {
 }
 
 // Enqueue a whole batch verification (nothing is waited for); the verdict lands in the context's pinned host words.
-static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
+static int verify_enqueue(mi355_bls_ctx* c, const uint8_t* d_sets, const uint8_t* h_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
     if (!c || !rnd) return MI355_BLS_ERR_ARG;
-    if (!d_sets || n == 0) return MI355_BLS_ERR_ARG;
+    if ((!d_sets && !h_sets) || n == 0) return MI355_BLS_ERR_ARG;
     if (c->pending) {
         g_err = "a batch submitted on this context has not been waited for";
         return MI355_BLS_ERR_ARG;
     }
     uint32_t B = (uint32_t)(n < c->num_threads ? n : c->num_threads);
-    int rc = run_shard(c, d_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
+    int rc = run_shard(c, d_sets, h_sets, n, B, 0, serial ? 1 : B, 0, n, serial, rnd, st);
     if (rc) return rc;
     k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[8], st));
@@ -1939,10 +2045,10 @@ static int verify_wait(mi355_bls_ctx* c) {
     c->timings[7] += fin;
     return (c->h_flags[0] == 0 && c->h_flags[1] == 1) ? 1 : 0;
 }
-static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
+static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, const uint8_t* h_sets, size_t n, const uint8_t rnd[32], int serial, hipStream_t st) {
     if (!c || !rnd) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;                      // bls_batch_verifier.nim:137-139, :312-314
-    int rc = verify_enqueue(c, d_sets, n, rnd, serial, st);
+    int rc = verify_enqueue(c, d_sets, h_sets, n, rnd, serial, st);
     if (rc) return rc;
     return verify_wait(c);
 }
@@ -1956,30 +2062,27 @@ extern "C" int mi355_bls_batch_submit_device(mi355_bls_ctx* c, const void* d_set
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamWaitEvent((hipStream_t)stream, after->ev[3], 0));
     }
-    return verify_enqueue(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);
+    return verify_enqueue(c, (const uint8_t*)d_sets, nullptr, n, rnd, 0, (hipStream_t)stream);
 }
 extern "C" int mi355_bls_batch_wait(mi355_bls_ctx* c) { return verify_wait(c); }
 
 extern "C" int mi355_bls_batch_verify_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream) {
-    return verify_common(c, (const uint8_t*)d_sets, n, rnd, 0, (hipStream_t)stream);
+    return verify_common(c, (const uint8_t*)d_sets, nullptr, n, rnd, 0, (hipStream_t)stream);
 }
 
 static int verify_host(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32], int serial) {
     if (!c || !rnd) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;
     if (!sets) return MI355_BLS_ERR_ARG;
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->d_sets, sets, n * 320, hipMemcpyHostToDevice, nullptr));
-    return verify_common(c, c->d_sets, n, rnd, serial, nullptr);
+    return verify_common(c, nullptr, (const uint8_t*)sets, n, rnd, serial, nullptr);      // staged through d_sets, slice by slice when n exceeds the capacity
 }
 
 extern "C" int mi355_bls_batch_verify(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 0); }
 extern "C" int mi355_bls_batch_verify_serial(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 1); }
 
-static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi, const uint8_t rnd[32],
+static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, const uint8_t* h_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi, const uint8_t rnd[32],
                          hipStream_t st, mi355_bls_ctx* after) {
-    if (!c || !rnd || n_total == 0 || !d_sets) return MI355_BLS_ERR_ARG;
+    if (!c || !rnd || n_total == 0 || (!d_sets && !h_sets)) return MI355_BLS_ERR_ARG;
     if (c->pending) {
         g_err = "a batch submitted on this context has not been waited for";
         return MI355_BLS_ERR_ARG;
@@ -1993,7 +2096,7 @@ static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, size_t n_total, u
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamWaitEvent(st, after->ev[3], 0));          // see mi355_bls_batch_submit_device
     }
-    int rc = run_shard(c, (const uint8_t*)d_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
+    int rc = run_shard(c, (const uint8_t*)d_sets, h_sets, n_total, B, chunk_lo, chunk_hi - chunk_lo, first, count, 0, rnd, st);
     if (rc) return rc;
     k_pack_blob<<<1, WAVE, 0, st>>>(c->d_states, c->d_flags, c->d_blob_out);
     HIPCHK(hipGetLastError());
@@ -2015,13 +2118,13 @@ static int shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) {
 extern "C" int mi355_bls_batch_shard_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
                                             const uint8_t rnd[32], void* stream, uint8_t out_fp12[576], int* out_ok) {
     if (!out_fp12 || !out_ok) return MI355_BLS_ERR_ARG;
-    int rc = shard_enqueue(c, d_sets, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, nullptr);
+    int rc = shard_enqueue(c, d_sets, nullptr, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, nullptr);
     if (rc) return rc;
     return shard_wait(c, out_fp12, out_ok);
 }
 extern "C" int mi355_bls_batch_shard_submit_device(mi355_bls_ctx* c, const void* d_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi,
                                                    const uint8_t rnd[32], void* stream, mi355_bls_ctx* after) {
-    return shard_enqueue(c, d_sets, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, after);
+    return shard_enqueue(c, d_sets, nullptr, n_total, chunk_lo, chunk_hi, rnd, (hipStream_t)stream, after);
 }
 extern "C" int mi355_bls_batch_shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) { return shard_wait(c, out_fp12, out_ok); }
 
@@ -2035,6 +2138,7 @@ extern "C" int mi355_bls_finalverify_shards(mi355_bls_ctx* c, const uint8_t* fp1
     HIPCHK(hipMemcpyAsync(&v, c->d_flags + 1, 4, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     c->have_gt = true;
+    c->gt_is_fv = false;
     return v == 1 ? 1 : 0;
 }
 
@@ -2059,7 +2163,7 @@ extern "C" int mi355_bls_finalverify_blobs_submit_device(mi355_bls_ctx* c, const
     }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt, c->d_flags + 3,
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(d_blobs)), (uint32_t)kk, 2, c->d_gt_fv, c->d_flags + 3,
                                (uint32_t)(stride_bytes / 4), 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_flags + 3, c->d_flags + 3, 4, hipMemcpyDeviceToHost, st));
@@ -2073,6 +2177,7 @@ extern "C" int mi355_bls_finalverify_wait(mi355_bls_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->fv_stream));
     c->have_gt = true;
+    c->gt_is_fv = true;
     return c->h_flags[3] == 1 ? 1 : 0;
 }
 
@@ -2099,44 +2204,80 @@ extern "C" int mi355_bls_shard_plan(size_t n_total, uint32_t num_threads, uint32
 // device g takes a contiguous block of chunks (its processSingleChunk work, :326-357), all shards are enqueued asynchronously,
 // the 576-byte committed states come back through pinned host memory, and device 0 merges them and runs the one final
 // exponentiation (:360-371).  d_sets[g] != nullptr: shard g's records are already resident on device g.
+// host time (us after the call began) at which each device's shard was handed to its stream in the last multi-device call of this thread
+static thread_local float g_multi_enq_us[64];
+static thread_local size_t g_multi_enq_n = 0;
+extern "C" size_t mi355_bls_debug_multi_enqueue_us(float* out, size_t cap) {
+    size_t k = g_multi_enq_n < cap ? g_multi_enq_n : cap;
+    for (size_t i = 0; i < k; i++) out[i] = g_multi_enq_us[i];
+    return g_multi_enq_n;
+}
+extern "C" int mi355_bls_debug_fail_next_enqueue(mi355_bls_ctx* c) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    c->fail_next_enqueue = true;
+    return 0;
+}
 static int verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const uint8_t* sets, const void* const d_sets[], size_t n, const uint8_t rnd[32]) {
     if (!ctxs || ngpu == 0 || ngpu > 64 || !rnd || (!sets && !d_sets)) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;
-    for (size_t g = 0; g < ngpu; g++)
-        if (!ctxs[g] || ctxs[g]->num_threads != ctxs[0]->num_threads) return MI355_BLS_ERR_ARG;
-    uint32_t nt = ctxs[0]->num_threads;
-    bool live[64] = {};
+    // first pass: the whole plan is validated before anything is enqueued, so that no argument error can strand a live shard
+    struct plan_t { uint32_t lo, hi; size_t first, count; } plan[64];
     for (size_t g = 0; g < ngpu; g++) {
-        uint32_t lo, hi;
-        size_t first, count;
-        mi355_bls_shard_plan(n, nt, (uint32_t)ngpu, (uint32_t)g, &lo, &hi, &first, &count);
-        if (count == 0) continue;                                 // more devices than chunks
-        mi355_bls_ctx* c = ctxs[g];
-        if (count > c->cap) return MI355_BLS_ERR_CAPACITY;
-        HIPCHK(hipSetDevice(c->device));
-        const void* src = d_sets ? d_sets[g] : nullptr;
-        if (!src) {
-            if (!sets) return MI355_BLS_ERR_ARG;
-            HIPCHK(hipMemcpyAsync(c->d_sets, sets + 320 * first, count * 320, hipMemcpyHostToDevice, nullptr));
-            src = c->d_sets;
+        if (!ctxs[g] || ctxs[g]->num_threads != ctxs[0]->num_threads) return MI355_BLS_ERR_ARG;
+        if (ctxs[g]->pending) {
+            g_err = "a batch submitted on this context has not been waited for";
+            return MI355_BLS_ERR_ARG;
         }
-        int rc = shard_enqueue(c, src, n, lo, hi, rnd, nullptr, nullptr);
-        if (rc) return rc;
-        live[g] = true;
+        mi355_bls_shard_plan(n, ctxs[0]->num_threads, (uint32_t)ngpu, (uint32_t)g, &plan[g].lo, &plan[g].hi, &plan[g].first, &plan[g].count);
+        if (plan[g].count && !(d_sets && d_sets[g]) && !sets) return MI355_BLS_ERR_ARG;
     }
+    // Host records: the caller's range is page-locked for the duration of the call, so that every device's copy is a real
+    // asynchronous DMA and device g does not wait for device g - 1's staging (from pageable memory hipMemcpyAsync blocks the host
+    // thread until the copy has been staged: 42 MB per 131 072-tuple shard).  If the range cannot be registered the copies are
+    // simply synchronous.
+    bool registered = false;
+    if (sets) {
+        bool any_host = false;
+        for (size_t g = 0; g < ngpu; g++) any_host = any_host || (plan[g].count && !(d_sets && d_sets[g]));
+        if (any_host) {
+            registered = hipHostRegister(const_cast<uint8_t*>(sets), n * 320, hipHostRegisterPortable) == hipSuccess;
+            if (!registered) (void)hipGetLastError();
+        }
+    }
+    bool live[64] = {};
+    int rc_keep = 0;
+    g_multi_enq_n = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (size_t g = 0; g < ngpu && !rc_keep; g++) {
+        g_multi_enq_us[g_multi_enq_n++] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+        if (plan[g].count == 0) continue;                          // more devices than chunks
+        mi355_bls_ctx* c = ctxs[g];
+        const void* src = d_sets ? d_sets[g] : nullptr;
+        // shard_enqueue stages host records itself (slice by slice when the shard exceeds the context's capacity)
+        int rc = shard_enqueue(c, src, src ? nullptr : sets + 320 * plan[g].first, n, plan[g].lo, plan[g].hi, rnd, nullptr, nullptr);
+        if (rc) rc_keep = rc;                                      // the shards already enqueued are waited for below
+        else live[g] = true;
+    }
+    std::string err_keep = g_err;
     std::vector<uint8_t> states;
     bool all_ok = true;
-    int rc_keep = 0;
     for (size_t g = 0; g < ngpu; g++) {
         if (!live[g]) continue;
         uint8_t st[576];
         int ok = 0;
         int rc = shard_wait(ctxs[g], st, &ok);                    // every enqueued shard is waited for, also after a failure
-        if (rc && !rc_keep) rc_keep = rc;
+        if (rc && !rc_keep) {
+            rc_keep = rc;
+            err_keep = g_err;
+        }
         all_ok = all_ok && ok;
         states.insert(states.end(), st, st + 576);
     }
-    if (rc_keep) return rc_keep;
+    if (registered) (void)hipHostUnregister(const_cast<uint8_t*>(sets));
+    if (rc_keep) {
+        g_err = err_keep;
+        return rc_keep;
+    }
     if (!all_ok) return 0;                                        // some update() failed (infinity public key)
     return mi355_bls_finalverify_shards(ctxs[0], states.data(), states.size() / 576);
 }
@@ -2221,7 +2362,7 @@ extern "C" int mi355_bls_fetch_stage(mi355_bls_ctx* c, int what, void* out, size
             return 0;
         case 4:
             if (out_bytes < 576 || !c->have_gt) return MI355_BLS_ERR_ARG;
-            HIPCHK(hipMemcpy(out, c->d_gt, 576, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(out, c->gt_is_fv ? c->d_gt_fv : c->d_gt, 576, hipMemcpyDeviceToHost));
             return 0;
         case 5:
             if (out_bytes < 576) return MI355_BLS_ERR_ARG;
@@ -2290,7 +2431,7 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     if (!d_pks) return MI355_BLS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
     HIPCHK(hipMemcpyAsync(c->d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
@@ -2632,7 +2773,7 @@ extern "C" void mi355_p2s_mult_pippenger(void* ret, const void* const points[], 
 static int deser_enqueue(mi355_bls_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint8_t* d_sigs, size_t n, uint32_t dflags, hipStream_t st) {
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
     if (dflags > 7) return MI355_BLS_ERR_ARG;
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
     k_deser<<<((uint32_t)n + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_pks, d_msgs, d_sigs, (uint32_t)n, dflags, c->d_sets, c->d_status, c->d_flags);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2710,7 +2851,7 @@ extern "C" int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* c, const 
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&c->deser_ms, c->ev_deser0, c->ev_deser1));
     if (fl[2]) return 0;                                   // some fromBytes failed: the caller never gets to batchVerify
-    return verify_common(c, c->d_sets, n, rnd, 0, st);
+    return verify_common(c, c->d_sets, nullptr, n, rnd, 0, st);
 }
 
 extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n,
@@ -2736,7 +2877,7 @@ extern "C" int mi355_bls_sign_sets_device(mi355_bls_ctx* c, const void* d_sks32,
     if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     uint32_t nb = ((uint32_t)n + WAVE - 1) / WAVE;
     k_sign_pk<<<nb, WAVE, 0, st>>>((const uint8_t*)d_sks32, (const uint8_t*)d_msgs32, (uint32_t)n, (uint8_t*)d_out_sets, c->d_status, c->d_flags);
@@ -2821,29 +2962,20 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
 // ------------------------------------------------------------------------------------------
 // aggregateVerify
 // ------------------------------------------------------------------------------------------
-extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig) {
-    if (!c || !sig) return MI355_BLS_ERR_ARG;
-    if (n == 0) return 0;                                   // "Spec precondition" (bls_sig_min_pubkey.nim:165-167)
-    if (!pks || !msgs || !msg_offsets) return MI355_BLS_ERR_ARG;
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
-    for (size_t i = 0; i < n; i++)
-        if (msg_offsets[i] > msg_offsets[i + 1]) return MI355_BLS_ERR_ARG;      // offsets must be non-decreasing (lengths are differences)
-    size_t total = msg_offsets[n];
-    if (total + (n + 1) * 4 > c->cap * 320 - n * 96) return MI355_BLS_ERR_CAPACITY;     // staged in d_sets behind the keys
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = nullptr;
+// One slice: pairs [0, n) of the slice (keys, rebased offsets and messages staged in d_sets), `with_sig`: the (-G1, sig) pair rides in
+// this slice.  Leaves the slice's committed state in d_states slot 0 (final: also runs the final exponentiation, one-slice calls).
+static int aggv_slice(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint32_t* offs, size_t n, bool with_sig, bool final, hipStream_t st) {
+    size_t total = offs[n];
     uint8_t* d_pk = c->d_sets;
     uint32_t* d_off = reinterpret_cast<uint32_t*>(c->d_sets + n * 96);
     uint8_t* d_msgs = c->d_sets + n * 96 + (n + 1) * 4;
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, 16, st));
     HIPCHK(hipMemcpyAsync(d_pk, pks, n * 96, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_off, msg_offsets, (n + 1) * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_msgs, msgs, total, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
-    uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE, nb1 = (n32 + 1 + WAVE - 1) / WAVE;
+    HIPCHK(hipMemcpyAsync(d_off, offs, (n + 1) * 4, hipMemcpyHostToDevice, st));
+    if (total) HIPCHK(hipMemcpyAsync(d_msgs, msgs, total, hipMemcpyHostToDevice, st));
+    uint32_t n32 = (uint32_t)n, nb = (n32 + WAVE - 1) / WAVE, npairs = n32 + (with_sig ? 1u : 0u), nb1 = (npairs + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
     bool all32 = c->xmd.valid;                      // every message 32 bytes long (signing roots): the batch path's hashing kernels
-    for (size_t i = 0; i < n && all32; i++) all32 = msg_offsets[i + 1] - msg_offsets[i] == 32;
+    for (size_t i = 0; i < n && all32; i++) all32 = offs[i + 1] - offs[i] == 32;
     if (all32) {
         // k_hash_map reads the message at offset 96 of a 320-byte record: the 32-byte messages are spread to that layout on the device
         // side of the staging buffer (keys | offsets | messages are packed at its start; the records go to d_comp)
@@ -2857,24 +2989,250 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
         k_hash_var<<<nb, WAVE, 0, st>>>(d_msgs, d_off, n32, c->dst, c->d_H, c->stride);
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
-    k_aggv_setup<<<nb1, WAVE, 0, st>>>(d_pk, n32, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
+    k_aggv_setup<<<nb1, WAVE, 0, st>>>(d_pk, n32, with_sig ? 1 : 0, reinterpret_cast<const uint32_t*>(c->d_msg + 4096), c->d_H, c->d_P, c->stride, c->d_flags);
     HIPCHK(hipEventRecord(c->ev[2], st));
-    launch_lines(c, n32 + 1, 0, st);
+    launch_lines(c, npairs, 0, st);
     HIPCHK(hipEventRecord(c->ev[3], st));
     {
-        int rcp = enqueue_line_products(c, n32 + 1, st, nullptr);
+        int rcp = enqueue_line_products(c, npairs, st, nullptr);
         if (rcp) return rcp;
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
-    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 3, c->d_gt, c->d_flags + 1, 144, 0);
+    k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, final ? 3 : 1, c->d_gt, c->d_flags + 1, 144, 0);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Any number of pairs: more than the context's capacity (pairs, or staged bytes: keys + offsets + messages share d_sets) are
+// processed in slices whose committed states are multiplied on the engine (k_state_mul), as for batchVerify.
+extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig) {
+    if (!c || !sig) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                                   // "Spec precondition" (bls_sig_min_pubkey.nim:165-167)
+    if (!pks || !msgs || !msg_offsets) return MI355_BLS_ERR_ARG;
+    for (size_t i = 0; i < n; i++)
+        if (msg_offsets[i] > msg_offsets[i + 1]) return MI355_BLS_ERR_ARG;      // offsets must be non-decreasing (lengths are differences)
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
+    HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
+    const size_t budget = c->cap * 320;
+    std::vector<uint32_t> offs;
+    size_t a = 0;
+    uint32_t slice = 0;
+    bool single = true;
+    while (a < n) {
+        // greedy slice [a, b): at most cap pairs, staged bytes within d_sets
+        size_t b = a, bytes = 4;
+        while (b < n && b - a < c->cap) {
+            size_t add = 96 + 4 + (msg_offsets[b + 1] - msg_offsets[b]);
+            if (bytes + add > budget) break;
+            bytes += add;
+            b++;
+        }
+        if (b == a) {
+            g_err = "one message does not fit the context's staging buffer";
+            return MI355_BLS_ERR_CAPACITY;
+        }
+        const bool last = b == n;
+        if (slice == 0) single = last;
+        offs.resize(b - a + 1);
+        for (size_t i = a; i <= b; i++) offs[i - a] = msg_offsets[i] - msg_offsets[a];
+        int rc = aggv_slice(c, (const uint8_t*)pks + 96 * a, msgs + msg_offsets[a], offs.data(), b - a, last, single, st);
+        if (rc) return rc;
+        if (!single) {
+            k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 1, slice ? 1 : 0, slice ? 0 : -1);
+            HIPCHK(hipStreamSynchronize(st));              // offs (host vector) and the staging buffer are reused by the next slice
+        }
+        a = b;
+        slice++;
+    }
+    if (!single) {
+        k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 0, 1, -1);
+        k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
+        HIPCHK(hipEventRecord(c->ev[5], st));
+        HIPCHK(hipGetLastError());
+    }
     uint32_t fl[2];
     HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     c->have_gt = true;
+    c->gt_is_fv = false;
     c->last_n = 0;
     int rc = collect_timings(c, 5);
     if (rc) return rc;
     return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
+}
+
+// ContextCoreAggregateVerify (blst_min_pubkey_sig_core.nim:305-414), the streaming form: init / update(publicKey, message) /
+// finish(signature).  The pairs are collected on the host (176 bytes + the message each) and verified by ONE device call at
+// finish - the reference's update also only queues work that commit / finalVerify later complete (blst's N_MAX = 8 pair buffer).
+// update returns 0 for the infinity public key (BLST_PK_IS_INFINITY: the reference's update returns false) and the context
+// stays failed until the next init.
+extern "C" int mi355_bls_aggv_init(mi355_bls_ctx* c) {
+    if (!c) return MI355_BLS_ERR_ARG;
+    c->av_pks.clear();
+    c->av_msgs.clear();
+    c->av_offs.assign(1, 0u);
+    c->av_failed = false;
+    return 0;
+}
+extern "C" int mi355_bls_aggv_update(mi355_bls_ctx* c, const void* pk, const uint8_t* msg, size_t msg_len) {
+    if (!c || !pk || (!msg && msg_len) || c->av_offs.empty() || msg_len > (1u << 30)) return MI355_BLS_ERR_ARG;
+    const uint8_t* p = (const uint8_t*)pk;
+    bool inf = true;
+    for (int i = 0; i < 96; i++) inf = inf && p[i] == 0;
+    if (inf) {
+        c->av_failed = true;
+        return 0;
+    }
+    c->av_pks.insert(c->av_pks.end(), p, p + 96);
+    if (msg_len) c->av_msgs.insert(c->av_msgs.end(), msg, msg + msg_len);
+    c->av_offs.push_back((uint32_t)c->av_msgs.size());
+    return 1;
+}
+extern "C" int mi355_bls_aggv_finish(mi355_bls_ctx* c, const void* sig) {
+    if (!c || !sig || c->av_offs.empty()) return MI355_BLS_ERR_ARG;
+    size_t n = c->av_offs.size() - 1;
+    int rc = 0;
+    // no pair seen: blst's finalverify has no GT accumulator set -> false; a failed update -> false
+    if (!c->av_failed && n) {
+        uint8_t dummy = 0;
+        rc = mi355_bls_aggregate_verify(c, c->av_pks.data(), c->av_msgs.empty() ? &dummy : c->av_msgs.data(), c->av_offs.data(), n, sig);
+    }
+    c->av_offs.clear();                                  // finish consumes the context: init again before the next use
+    c->av_pks.clear();
+    c->av_msgs.clear();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Point-sharded MSM across devices ("MSM"): every device computes the full-width partial sum of its
+// share of the points (blst_p1 / blst_p2, Jacobian), the partials are added (blst_p1_add_or_double, blst_abi.nim:278) - 144 or
+// 288 bytes per device is all that is exchanged.
+// ------------------------------------------------------------------------------------------
+template <class F>
+static int jac_sum_device(mi355_bls_ctx* c, uint8_t* ret, const void* d_parts, size_t k, size_t stride_bytes, hipStream_t st) {
+    constexpr size_t JACB = (sizeof(F) == sizeof(fp) ? 96 : 192) / 2 * 3;
+    if (!c || !ret || !d_parts || k == 0 || k > 4096 || stride_bytes < JACB || (stride_bytes & 3)) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    k_jac_sum_blst<F><<<1, WAVE, 0, st>>>((const uint32_t*)d_parts, (uint32_t)k, (uint32_t)(stride_bytes / 4), c->d_agg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ret, c->d_agg, JACB, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->agg_valid = false;                                // d_agg doubles as the batch path's aggregate-signature buffer
+    return 0;
+}
+template <class F>
+static int jac_sum_host(mi355_bls_ctx* c, uint8_t* ret, const uint8_t* parts, size_t k) {
+    constexpr size_t JACB = (sizeof(F) == sizeof(fp) ? 96 : 192) / 2 * 3;
+    if (!c || !ret || !parts || k == 0 || k * JACB > 2048 * 2 * G1W * 4) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_export, parts, k * JACB, hipMemcpyHostToDevice, nullptr));
+    return jac_sum_device<F>(c, ret, c->d_export, k, JACB, nullptr);
+}
+extern "C" int mi355_bls_p1s_add(mi355_bls_ctx* c, uint8_t ret_p1[144], const uint8_t* parts, size_t k) { return jac_sum_host<fp>(c, ret_p1, parts, k); }
+extern "C" int mi355_bls_p2s_add(mi355_bls_ctx* c, uint8_t ret_p2[288], const uint8_t* parts, size_t k) { return jac_sum_host<fp2>(c, ret_p2, parts, k); }
+extern "C" int mi355_bls_p1s_add_device(mi355_bls_ctx* c, uint8_t ret_p1[144], const void* d_parts, size_t k, size_t stride_bytes, void* stream) {
+    return jac_sum_device<fp>(c, ret_p1, d_parts, k, stride_bytes, (hipStream_t)stream);
+}
+// this device's partial of a point-sharded MSM, left in DEVICE memory (d_out_p1, 144 B) behind everything else on `stream`: the
+// send buffer of the collective that gathers the partials; nothing is waited for
+extern "C" int mi355_bls_p1s_mult_pippenger_partial_device(mi355_bls_ctx* c, void* d_out_p1, const void* d_points, size_t npoints, const void* d_scalars,
+                                                           size_t nbits, void* stream) {
+    if (!c || !d_out_p1 || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    if (npoints == 0) {
+        HIPCHK(hipMemsetAsync(d_out_p1, 0, 144, st));
+        return 0;
+    }
+    if (!d_points || !d_scalars) return MI355_BLS_ERR_ARG;
+    int rc = msm_enqueue<fp>(c, c->msm, d_points, npoints, d_scalars, 32, nbits, st, false, true);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d_out_p1, c->msm->out, 144, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// One host thread, ngpu contexts (one per device): device g takes points [off_g, off_g + cnt_g) (balanced contiguous blocks), all
+// partial MSMs are enqueued before any is waited for, the partials return through pinned host memory and ctxs[0] adds them.
+// Host arrays (pts / sc) or per-device resident arrays (d_pts[g] / d_sc[g] hold shard g).
+template <class F>
+static int msm_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t* ret, const uint8_t* pts, const uint8_t* sc, const void* const d_pts[],
+                     const void* const d_sc[], size_t npoints, size_t nbits) {
+    constexpr size_t AFFB = sizeof(F) == sizeof(fp) ? 96 : 192, JACB = AFFB / 2 * 3;
+    if (!ctxs || ngpu == 0 || ngpu > 64 || !ret || nbits == 0 || nbits > 256 || npoints > (1u << 28)) return MI355_BLS_ERR_ARG;
+    if (npoints == 0) {
+        std::memset(ret, 0, JACB);
+        return 0;
+    }
+    for (size_t g = 0; g < ngpu; g++)
+        if (!ctxs[g]) return MI355_BLS_ERR_ARG;
+    if (!(pts && sc) && !(d_pts && d_sc)) return MI355_BLS_ERR_ARG;
+    size_t base = npoints / ngpu, rem = npoints % ngpu;
+    bool reg_p = false, reg_s = false;
+    if (pts) {                                           // page-lock the caller's arrays: every device's copy is then a real asynchronous DMA
+        reg_p = hipHostRegister(const_cast<uint8_t*>(pts), npoints * AFFB, hipHostRegisterPortable) == hipSuccess;
+        reg_s = hipHostRegister(const_cast<uint8_t*>(sc), npoints * 32, hipHostRegisterPortable) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    bool live[64] = {};
+    int rc = 0;
+    for (size_t g = 0; g < ngpu && !rc; g++) {
+        size_t off = g < rem ? (base + 1) * g : base * g + rem, cnt = base + (g < rem ? 1 : 0);
+        if (cnt == 0) continue;
+        mi355_bls_ctx* c = ctxs[g];
+        if (hipSetDevice(c->device) != hipSuccess) { g_err = "hipSetDevice"; rc = MI355_BLS_ERR_HIP; break; }
+        const void *dp = d_pts ? d_pts[g] : nullptr, *ds = d_sc ? d_sc[g] : nullptr;
+        if (!dp || !ds) {
+            if (!pts || !sc) { rc = MI355_BLS_ERR_ARG; break; }
+            rc = msm_reserve(c, c->msm, cnt, pip_plan(cnt, nbits), AFFB);
+            if (rc) break;
+            if (hipMemcpyAsync(c->msm->d_pts, pts + off * AFFB, cnt * AFFB, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+                hipMemcpyAsync(c->msm->d_sc, sc + off * 32, cnt * 32, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+                g_err = "hipMemcpyAsync (MSM shard staging)";
+                rc = MI355_BLS_ERR_HIP;
+                break;
+            }
+            dp = c->msm->d_pts;
+            ds = c->msm->d_sc;
+        }
+        rc = msm_enqueue<F>(c, c->msm, dp, cnt, ds, 32, nbits, nullptr, false, true);
+        if (rc) break;
+        if (hipMemcpyAsync(c->h_flags + 160, c->msm->out, JACB, hipMemcpyDeviceToHost, nullptr) != hipSuccess) { g_err = "hipMemcpyAsync (MSM partial)"; rc = MI355_BLS_ERR_HIP; break; }
+        live[g] = true;
+    }
+    std::vector<uint8_t> parts;
+    for (size_t g = 0; g < ngpu; g++) {                  // every device that was handed work is waited for, also after a failure
+        if (!live[g]) continue;
+        (void)hipSetDevice(ctxs[g]->device);
+        if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) { g_err = "hipStreamSynchronize (MSM shard)"; rc = MI355_BLS_ERR_HIP; }
+        const uint8_t* h = reinterpret_cast<const uint8_t*>(ctxs[g]->h_flags + 160);
+        parts.insert(parts.end(), h, h + JACB);
+    }
+    if (reg_p) (void)hipHostUnregister(const_cast<uint8_t*>(pts));
+    if (reg_s) (void)hipHostUnregister(const_cast<uint8_t*>(sc));
+    if (rc) return rc;
+    return jac_sum_host<F>(ctxs[0], ret, parts.data(), parts.size() / JACB);
+}
+extern "C" int mi355_bls_p1s_mult_pippenger_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p1[144], const void* const points[], size_t npoints,
+                                                  const uint8_t* const scalars[], size_t nbits) {
+    if (npoints && (!points || !points[0] || !scalars || !scalars[0])) return MI355_BLS_ERR_ARG;
+    return msm_multi<fp>(ctxs, ngpu, ret_p1, npoints ? (const uint8_t*)points[0] : nullptr, npoints ? scalars[0] : nullptr, nullptr, nullptr, npoints, nbits);
+}
+extern "C" int mi355_bls_p2s_mult_pippenger_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p2[288], const void* const points[], size_t npoints,
+                                                  const uint8_t* const scalars[], size_t nbits) {
+    if (npoints && (!points || !points[0] || !scalars || !scalars[0])) return MI355_BLS_ERR_ARG;
+    return msm_multi<fp2>(ctxs, ngpu, ret_p2, npoints ? (const uint8_t*)points[0] : nullptr, npoints ? scalars[0] : nullptr, nullptr, nullptr, npoints, nbits);
+}
+extern "C" int mi355_bls_p1s_mult_pippenger_multi_device(mi355_bls_ctx* const ctxs[], size_t ngpu, uint8_t ret_p1[144], const void* const d_points[], size_t npoints,
+                                                         const void* const d_scalars[], size_t nbits) {
+    if (npoints && (!d_points || !d_scalars)) return MI355_BLS_ERR_ARG;
+    return msm_multi<fp>(ctxs, ngpu, ret_p1, nullptr, nullptr, d_points, d_scalars, npoints, nbits);
+}
+/* how mi355_bls_p1s_mult_pippenger_multi cuts npoints into ngpu contiguous shards */
+extern "C" void mi355_bls_msm_shard_range(size_t npoints, uint32_t world, uint32_t rank, size_t* first, size_t* count) {
+    size_t base = world ? npoints / world : 0, rem = world ? npoints % world : 0;
+    *first = rank < rem ? (base + 1) * rank : base * rank + rem;
+    *count = base + (rank < rem ? 1 : 0);
 }

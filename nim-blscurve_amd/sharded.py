@@ -55,3 +55,27 @@ def batch_verify_sharded(cache, local_sets_ptr, n_total, rank, world, secureRand
     if not all(b[STATE_BYTES] == 1 for b in live):
         return False                        # some update() failed (infinity public key)
     return cache.finalverify_shards([b[:STATE_BYTES] for b in live])
+
+
+def msm_shard_range(npoints, world, rank):
+    """(first, count) of the points rank `rank` takes in a point-sharded MSM: balanced contiguous blocks
+    (mi355_bls_msm_shard_range; SURVEY.md section 8(e), "MSM")."""
+    base, rem = divmod(npoints, world)
+    first = (base + 1) * rank if rank < rem else base * rank + rem
+    return first, base + (1 if rank < rem else 0)
+
+
+P1_BYTES = 144
+
+
+def msm_sharded(local_partial, add_partials, npoints, rank, world, all_gather):
+    """Point-sharded blst_p1s_mult_pippenger across ranks (benchmarks/bls12381_msm_g1.nim:47-59 shape over GPUs):
+    local_partial(first, count) -> this rank's 144-byte blst_p1 partial (all zeros for an empty shard),
+    all_gather(bytes) -> every rank's bytes, add_partials([bytes]) -> their sum (rank 0 only; blst_p1_add_or_double).
+    Returns the blst_p1 result on rank 0, None elsewhere.  One exchange of 144 bytes per rank."""
+    first, count = msm_shard_range(npoints, world, rank)
+    part = local_partial(first, count) if count else bytes(P1_BYTES)
+    parts = all_gather(part)
+    if rank != 0:
+        return None
+    return add_partials(parts)

@@ -500,6 +500,54 @@ int oracle_batch_verify(const uint8_t* sets, size_t n, const uint8_t rnd[32], in
     return res;
 }
 
+/* aggregateVerify (bls_sig_min_pubkey.nim:153-199 over ContextCoreAggregateVerify, blst_min_pubkey_sig_core.nim:305-414): update per
+ * (public key, message) pair WITHOUT blinding (chk_n_aggr_pk_in_g1: the pair (pk_i, H(m_i)) enters the Miller loop as it is), then
+ * finish(signature): the signature is aggregated, commit, finalverify.  Messages: msgs[offs[i] .. offs[i+1]).  Pairs are split over
+ * OpenMP threads, one pairing context each, merged in order (the GT product is commutative).  gt_out (optional): 576 B. */
+int oracle_aggregate_verify(const uint8_t* pks, const uint8_t* msgs, const uint32_t* offs, size_t n, const uint8_t sig192[192], uint8_t* gt_out) {
+    if (n == 0) return 0;
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    if ((size_t)T > n) T = (int)n;
+    pctx* ctx = (pctx*)malloc((size_t)T * sizeof(pctx));
+    int* ok = (int*)malloc((size_t)T * sizeof(int));
+    uint8_t zero[32] = {0};
+    size_t base = n / T, rem = n % T;
+#pragma omp parallel for schedule(static, 1)
+    for (long c = 0; c < (long)T; c++) {
+        size_t off = (size_t)c < rem ? (base + 1) * c : base * c + rem, len = (size_t)c < rem ? base + 1 : base;
+        ctx_init(&ctx[c], zero, NULL, 0, DST_SIG, sizeof(DST_SIG) - 1);
+        ok[c] = 1;
+        for (size_t i = off; i < off + len; i++) {
+            g1a pk = ld_g1a(pks + 96 * i);
+            if (pk.inf) { ok[c] = 0; break; }                     /* BLST_PK_IS_INFINITY -> update false */
+            g2a h = hash_to_g2(msgs + offs[i], offs[i + 1] - offs[i], DST_SIG, sizeof(DST_SIG) - 1);
+            ctx[c].Q[ctx[c].nq] = h; ctx[c].P[ctx[c].nq] = pk; ctx[c].nq++;
+            if (ctx[c].nq == 8) ctx_flush(&ctx[c]);
+        }
+        ctx_flush(&ctx[c]);
+    }
+    int all = 1;
+    for (int c = 0; c < T; c++) all &= ok[c];
+    int res = 0;
+    if (all) {
+        for (int c = 1; c < T; c++) ctx_merge(&ctx[0], &ctx[c]);
+        g2a sg = ld_g2a(sig192);
+        if (!sg.inf) { g2j sj = g2_from_aff(&sg); ctx[0].aggr = g2_add(&ctx[0].aggr, &sj); }
+        res = ctx_finalverify(&ctx[0], gt_out, NULL);
+    }
+    free(ctx); free(ok);
+    return res;
+}
+/* sum of n affine G2 points (aggregate signature of test inputs) */
+void oracle_g2_sum(const uint8_t* pts, size_t n, uint8_t out192[192]) {
+    g2j acc = g2_inf();
+    for (size_t i = 0; i < n; i++) { g2a a = ld_g2a(pts + 192 * i); if (a.inf) continue; g2j j = g2_from_aff(&a); acc = g2_add(&acc, &j); }
+    g2a r = g2_to_aff(&acc); st_g2a(out192, &r);
+}
+
 void oracle_hash_to_g2(const uint8_t* msg, size_t mlen, const uint8_t* dst, size_t dlen, uint8_t out192[192]) {
     g2a h = hash_to_g2(msg, mlen, dst, dlen); st_g2a(out192, &h);
 }
@@ -739,6 +787,42 @@ void oracle_msm_g2(const uint8_t* pts, const uint8_t* scalars, size_t n, int sby
 #pragma omp critical
         acc = g2_add(&acc, &loc);
     }
+    g2a r = g2_to_aff(&acc); st_g2a(out192, &r);
+}
+/* The same bucket method on G2 (blst_p2s_mult_pippenger, blst_abi.nim:358-362; call site blst_min_pubkey_sig_core.nim:639-646), scalars
+ * `sbytes` apart: the checker of the device G2 MSM at sizes the naive loop above does not finish in seconds. */
+static uint32_t msm_digit_n(const uint8_t* k, int bit0, int c, int nbits, int sbytes) {
+    uint32_t d = 0;
+    for (int j = 0; j < c && bit0 + j < nbits && ((bit0 + j) >> 3) < sbytes; j++) d |= (uint32_t)((k[(bit0 + j) >> 3] >> ((bit0 + j) & 7)) & 1) << j;
+    return d;
+}
+void oracle_msm_g2_pippenger(const uint8_t* pts, const uint8_t* scalars, size_t n, int sbytes, int nbits, uint8_t out192[192]) {
+    int c = 1;
+    while (c < 14 && ((size_t)1 << (c + 3)) <= n) c++;
+    int nwin = (nbits + c - 1) / c;
+    g2j* win = (g2j*)malloc((size_t)nwin * sizeof(g2j));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int w = 0; w < nwin; w++) {
+        size_t nb = (size_t)1 << c;
+        g2j* B = (g2j*)malloc(nb * sizeof(g2j));
+        for (size_t b = 0; b < nb; b++) B[b] = g2_inf();
+        for (size_t i = 0; i < n; i++) {
+            uint32_t d = msm_digit_n(scalars + (size_t)sbytes * i, w * c, c, nbits, sbytes);
+            if (!d) continue;
+            g2a a = ld_g2a(pts + 192 * i); g2j j = g2_from_aff(&a);
+            B[d] = g2_add(&B[d], &j);
+        }
+        g2j run = g2_inf(), acc = g2_inf();
+        for (size_t b = nb - 1; b >= 1; b--) { run = g2_add(&run, &B[b]); acc = g2_add(&acc, &run); }
+        win[w] = acc;
+        free(B);
+    }
+    g2j acc = g2_inf();
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int j = 0; j < c; j++) acc = g2_dbl(&acc);
+        acc = g2_add(&acc, &win[w]);
+    }
+    free(win);
     g2a r = g2_to_aff(&acc); st_g2a(out192, &r);
 }
 /* combine (blst_min_pubkey_sig_core.nim:570-647): scalars = u64 words 3,2,1,0 of a SHA-256 chain seeded with rnd itself, zeros

@@ -31,6 +31,9 @@ def lib():
         L.oracle_msm_g1_pippenger.argtypes = [cp, cp, sz, i32, cp]
         L.oracle_core_verify.argtypes = [cp, cp, sz, cp]
         L.oracle_msm_g2.argtypes = [cp, cp, sz, i32, i32, cp]
+        L.oracle_msm_g2_pippenger.argtypes = [cp, cp, sz, i32, i32, cp]
+        L.oracle_aggregate_verify.argtypes = [cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp, vp]
+        L.oracle_g2_sum.argtypes = [cp, sz, cp]
         L.oracle_combine.argtypes = [cp, cp, cp, sz, cp, cp, vp]
         L.oracle_set_num_threads.argtypes = [i32]
         L.oracle_set_num_threads.restype = None
@@ -158,6 +161,30 @@ def deserialize_sets_ex(pks, msgs, sigs, flags):
 def msm_g2(pts, scalars, nbits=255, sbytes=32):
     o = ctypes.create_string_buffer(192)
     lib().oracle_msm_g2(pts, scalars, len(pts) // 192, sbytes, nbits, o)
+    return o.raw
+
+
+def msm_g2_pippenger(pts, scalars, nbits=255, sbytes=32):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_msm_g2_pippenger(pts, scalars, len(pts) // 192, sbytes, nbits, o)
+    return o.raw
+
+
+def aggregate_verify(pks, msgs, sig, gt=False):
+    """pks: list of 96-byte keys (or their concatenation), msgs: list of byte strings, sig: 192 bytes -> verdict (and the GT value)."""
+    pkb = pks if isinstance(pks, (bytes, bytearray)) else b"".join(pks)
+    offs = [0]
+    for x in msgs:
+        offs.append(offs[-1] + len(x))
+    arr = (ctypes.c_uint32 * len(offs))(*offs)
+    g = ctypes.create_string_buffer(576)
+    ok = bool(lib().oracle_aggregate_verify(bytes(pkb), b"".join(msgs) or b"\0", arr, len(msgs), sig, g))
+    return (ok, g.raw) if gt else ok
+
+
+def g2_sum(pts):
+    o = ctypes.create_string_buffer(192)
+    lib().oracle_g2_sum(pts, len(pts) // 192, o)
     return o.raw
 
 

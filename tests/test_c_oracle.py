@@ -127,3 +127,47 @@ def test_combine_and_g2_msm_restatements():
             want = o.g2_add(want, o.g2_mul(q, k % (1 << nbits)))
         got = co.msm_g2(sigs, b"".join(k.to_bytes(sb, "little") for k in K), nbits, sb)
         assert got == o.g2_to_blst_affine(want)
+
+
+def test_g2_pippenger_restatement_equals_naive():
+    """oracle_msm_g2_pippenger (checker of the device G2 MSM at 2^18 points) == the naive loop, which the test above pins to the
+    python oracle; both scalar spacings."""
+    import random
+    g = golden("batch")["combine"]
+    sigs = bytes.fromhex(g["sigs"])
+    k = len(sigs) // 192
+    rng = random.Random(21)
+    n = 700
+    pts = b"".join(sigs[192 * rng.randrange(k):][:192] for _ in range(n))
+    for nbits, sb in ((64, 8), (255, 32), (130, 17)):
+        sc = bytes(rng.getrandbits(8) for _ in range(sb * n))
+        assert co.msm_g2_pippenger(pts, sc, nbits, sb) == co.msm_g2(pts, sc, nbits, sb), nbits
+
+
+def test_aggregate_verify_restatement():
+    """oracle_aggregate_verify (checker of the device aggregateVerify at 1 024 ... 20 000 pairs) against the KAT-pinned python oracle:
+    verdicts on the n9 fixture (valid, rotated messages, missing pair, infinity key), the forged pair (passes: no blinding), messages
+    of other lengths, and the GT value == the python oracle's final exponentiation of the same product."""
+    c = [x for x in golden("batch")["cases"] if x["name"] == "n9"][0]
+    rec = bytes.fromhex(c["sets"])
+    n = c["n"]
+    pks = [rec[320 * i:320 * i + 96] for i in range(n)]
+    msgs = [rec[320 * i + 96:320 * i + 128] for i in range(n)]
+    sigs = b"".join(rec[320 * i + 128:320 * i + 320] for i in range(n))
+    agg = co.g2_sum(sigs)
+    assert agg == o.g2_to_blst_affine(o.aggregate_g2([o.g2_from_blst_affine(sigs[192 * i:192 * i + 192]) for i in range(n)]))
+    ok, gt = co.aggregate_verify(pks, msgs, agg, gt=True)
+    assert ok is True
+    assert o.aggregate_verify([o.g1_from_blst_affine(p) for p in pks], msgs, o.g2_from_blst_affine(agg)) is True
+    assert co.aggregate_verify(pks, msgs[1:] + msgs[:1], agg) is False
+    assert co.aggregate_verify(pks[:-1], msgs[:-1], agg) is False
+    assert co.aggregate_verify([bytes(96)] + pks[1:], msgs, agg) is False
+    f = [x for x in golden("batch")["cases"] if x["name"] == "forged_pair"][0]
+    fr = bytes.fromhex(f["sets"])
+    fp, fm = [fr[320 * i:320 * i + 96] for i in range(f["n"])], [fr[320 * i + 96:320 * i + 128] for i in range(f["n"])]
+    assert co.aggregate_verify(fp, fm, co.g2_sum(b"".join(fr[320 * i + 128:320 * i + 320] for i in range(f["n"])))) is True
+    texts = [b"", b"a", b"Mr F was here", bytes(200)]
+    keys = [o.keygen_seed(i) for i in range(4)]
+    sig = o.g2_to_blst_affine(o.aggregate_g2([o.sign(sk, t) for (pk, sk), t in zip(keys, texts)]))
+    pkb = [o.g1_to_blst_affine(pk) for pk, sk in keys]
+    assert co.aggregate_verify(pkb, texts, sig) is True and co.aggregate_verify(pkb, [b"x"] + texts[1:], sig) is False

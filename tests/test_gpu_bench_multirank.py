@@ -36,3 +36,29 @@ def test_rccl_exchange_with_one_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["exchange"] == {"mode": "device"} and d["value"] > 0
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes itself (before any GPU call of its own),
+    relays rank 0's JSON line and returns 0; both ranks share device 0 and exchange over gloo (the documented test hook).  The
+    multi-GPU MSM rows ride along."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_ALL_ON_DEVICE0="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4096", "--no-cpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["exchange"]["mode"] == "host" and d["value"] > 0
+    msm = d["multi_gpu"]["g1_msm"]
+    assert msm["weak_2^20_per_gpu"]["points_total"] == 2 << 20 and msm["weak_2^20_per_gpu"]["points_per_s"] > 0
+    assert msm["strong_2^20_total"]["points_total"] == 1 << 20
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr

@@ -1,0 +1,129 @@
+"""Capacity-free batchVerify: the reference cache holds per-thread pairing contexts only and accepts any input.len
+(bls_batch_verifier.nim:108-119,141); the device context's workspace is sized for max_sets tuples and larger batches are
+processed in slices whose committed states are merged on the device (blst_pairing_merge).  Checked against the C restatement:
+identical blinding scalars (the chain of a chunk that a slice boundary cuts is carried over), GT value and verdict."""
+import hashlib
+import struct
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+RND = hashlib.sha256(b"Mr F was here").digest()
+
+
+@pytest.fixture(scope="module")
+def m():
+    import __graft_entry__ as ge
+    ge.build()
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def batch():
+    import c_oracle as co
+    n = 3 * 4096 + 17
+    return co.make_batch(n, seed=31337), n
+
+
+@pytest.mark.parametrize("nt", [4096, 4, 1000])
+def test_sliced_batch_equals_oracle(m, batch, nt):
+    """cap = 4096, n = 3 * 4096 + 17 -> 4 balanced slices.  nt = 4: every chunk (3076 tuples) is cut by slice boundaries; nt = 1000:
+    chunks of 12 / 13 tuples, most slice boundaries fall inside a chunk; nt = 4096: 3 / 4 tuples per chunk."""
+    import c_oracle as co
+    rec, n = batch
+    ok, st = co.batch_verify(rec, RND, nt, stages=True)
+    assert ok
+    cache = m.BatchedBLSVerifierCache.init(max_sets=4096, numThreads=nt)
+    for coop in (True, False):
+        cache.set_cooperative(coop)
+        assert m.batchVerifyParallel(cache, rec, RND) is True
+        assert cache.fetch(4, 576) == st["gt"]
+    # the last slice's blinding scalars are the oracle's scalars of those tuples (fetch_stage shows the last slice)
+    left, last = n, 0
+    for k in range(4, 0, -1):                       # balanced slices: ceil(left / slices left)
+        last = (left + k - 1) // k
+        left -= last
+    assert list(struct.unpack("<%dQ" % last, cache.fetch(0, 8 * last))) == st["r"][n - last:]
+    # device-resident records through the asynchronous entry points
+    import torch
+    d = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    cache.submit_device(d.data_ptr(), n, RND)
+    assert cache.wait() is True and cache.fetch(4, 576) == st["gt"]
+    # tampered tuple in the third slice; infinity public key in the second
+    bad = bytearray(rec)
+    bad[320 * 9000 + 96] ^= 1
+    okb, stb = co.batch_verify(bytes(bad), RND, nt, stages=True)
+    assert not okb
+    assert m.batchVerifyParallel(cache, bytes(bad), RND) is False and cache.fetch(4, 576) == stb["gt"]
+    inf = bytearray(rec)
+    inf[320 * 5000:320 * 5000 + 96] = bytes(96)
+    assert co.batch_verify(bytes(inf), RND, nt) is False
+    assert m.batchVerifyParallel(cache, bytes(inf), RND) is False
+    cache.close()
+
+
+def test_sliced_serial_chain_and_dispatch(m, batch):
+    """batchVerifySerial's single chain over a sliced batch (the host computes the whole chain, every slice uploads its part),
+    and batchVerify's dispatch on a small context."""
+    import c_oracle as co
+    rec, n = batch
+    ok, st = co.batch_verify(rec, RND, 0, stages=True)
+    assert ok
+    cache = m.BatchedBLSVerifierCache.init(max_sets=4096, numThreads=1)
+    assert m.batchVerifySerial(cache, rec, RND) is True and cache.fetch(4, 576) == st["gt"]
+    assert m.batchVerify(cache, rec, RND) is True                       # numThreads = 1 -> serial path (:440)
+    bad = bytearray(rec)
+    bad[320 * (n - 1) + 130] ^= 4
+    assert m.batchVerifySerial(cache, bytes(bad), RND) is False
+    cache.close()
+
+
+def test_sliced_shards_and_multi(m, batch):
+    """Shards larger than their contexts: 3 contexts of 1500 sets for 12 305 tuples (shards of ~4100 -> 3 slices each), the merged
+    GT equals the whole-batch GT of the C restatement; the cache-less entry on a default context."""
+    import c_oracle as co
+    rec, n = batch
+    nt = 96
+    ok, st = co.batch_verify(rec, RND, nt, stages=True)
+    assert ok
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=1500, numThreads=nt) for _ in range(3)]
+    assert m.batchVerifyMulti(caches, rec, RND) is True
+    assert caches[0].fetch(4, 576) == st["gt"]
+    bad = bytearray(rec)
+    bad[320 * 12000 + 97] ^= 1
+    assert m.batchVerifyMulti(caches, bytes(bad), RND) is False
+    for c in caches:
+        c.close()
+
+
+def test_multi_driver_survives_an_enqueue_failure(m):
+    """mi355_bls_batch_verify_multi: a failure while enqueuing shard 2 of 3 (injected) is reported, the shards already submitted
+    are waited for, and all three contexts are usable right after; a context with a batch still pending is refused BEFORE anything
+    is enqueued.  Also prints the host-side start skew between the devices' shards."""
+    import ctypes
+    import c_oracle as co
+    n, nt = 3000, 48
+    rec = co.make_batch(n, seed=99)
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=1000, numThreads=nt) for _ in range(3)]
+    assert m.batchVerifyMulti(caches, rec, RND) is True
+    L = m.lib()
+    assert L.mi355_bls_debug_fail_next_enqueue(caches[1]._h) == 0
+    with pytest.raises(m.BlsGpuError, match="injected"):
+        m.batchVerifyMulti(caches, rec, RND)
+    assert m.batchVerifyMulti(caches, rec, RND) is True             # nothing left pending on contexts 0 and 2
+    for c in caches:
+        assert m.batchVerifyParallel(c, rec[:320 * 500], RND) is True
+    # a pending batch on context 2: refused in the validation pass, contexts 0 and 1 untouched
+    import torch
+    d = torch.frombuffer(bytearray(rec[:320 * 800]), dtype=torch.uint8).cuda()
+    caches[2].submit_device(d.data_ptr(), 800, RND)
+    with pytest.raises(m.BlsGpuError, match="not been waited for"):
+        m.batchVerifyMulti(caches, rec, RND)
+    assert caches[2].wait() is True
+    assert m.batchVerifyMulti(caches, rec, RND) is True
+    us = (ctypes.c_float * 8)()
+    k = L.mi355_bls_debug_multi_enqueue_us(us, 8)
+    print("host-side enqueue times of the shards (us after the call began):", [round(us[i], 1) for i in range(k)])
+    assert k == 3 and us[0] <= us[1] <= us[2]
+    for c in caches:
+        c.close()

@@ -156,3 +156,24 @@ def test_g2_pippenger_linearity_at_2_18(m):
     b = g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, k2.tobytes(), 255))
     c = g2_jac_to_affine(m.blst_p2s_mult_pippenger(pts, s.tobytes(), 255))
     assert o.g2_add(a, b) == c and c is not None
+
+
+def test_g2_pippenger_vs_c_oracle_at_2_18(m):
+    """G2 MSM at 2^18 points against the C restatement of the bucket method on G2 (oracle_msm_g2_pippenger): 64-bit scalars as
+    `combine` passes them (blst_min_pubkey_sig_core.nim:639-646), 8 bytes apart, and 255-bit ones."""
+    import random
+    import numpy as np
+    import c_oracle as co
+    from util import g2_jac_to_affine
+    rng = random.Random(18)
+    n = 1 << 18
+    h = co.hash_to_g2(b"g2 msm 2^18 parity", o.DST_SIG)
+    base = [co.g2_mul(h, rng.randrange(1, o.R)) for _ in range(256)]
+    pts = b"".join(base[i % 256] for i in range(n))
+    for nbits, sb in ((64, 8), (255, 32)):
+        sc = np.random.default_rng(nbits).integers(0, 256, size=(n, sb), dtype=np.uint8)
+        if nbits == 255:
+            sc[:, 31] &= 0x7f
+        sc = sc.tobytes()
+        got = m.blst_p2s_mult_pippenger(pts, sc, nbits)
+        assert o.g2_to_blst_affine(g2_jac_to_affine(got)) == co.msm_g2_pippenger(pts, sc, nbits, sb), nbits

@@ -237,3 +237,47 @@ def test_known_on_curve_compressed_form(m, cache):
     assert (False, out, st) == co.deserialize_sets_ex(pk, ms4, sg, 4)
     ok, out, st = m.deserializeSetsEx(cache, pk, ms4, sg)
     assert list(st) == [0, 2, 5, 3]
+
+
+def test_headline_size_distinct_tuples_vs_c_oracle(m):
+    """fromBytes at the headline batch size: 65 536 DISTINCT tuples (device signer) with invalid encodings sprinkled over the
+    batch - statuses and every surviving record equal the C restatement's (decompression by square root, subgroup membership by
+    [r]P), and the wire-format batch verify of the clean batch is true."""
+    import torch
+    import bench
+    import c_oracle as co
+    rng = random.Random(65536)
+    n = 65536
+    dev = torch.device("cuda", 0)
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n)
+    rec = bytes(bench.sign_records(m, cache, dev, range(5_000_000, 5_000_000 + n)).cpu().numpy())
+    pk, ms, sg = co.compress_sets(rec)
+    rnd = o.sha256(b"Mr F was here")
+    v, st = m.batchVerifyCompressed(cache, pk, ms, sg, rnd)
+    assert v is True and st == bytes(n)
+    pkb, sgb = bytearray(pk), bytearray(sg)
+    bad_pk = [o.g1_compress(_curve_point_g1(rng)) for _ in range(3)]            # on the curve, not in G1
+    bad_sg = [o.g2_compress(_curve_point_g2(rng)) for _ in range(3)]
+    touched = set()
+    for j in range(40):
+        i = rng.randrange(n)
+        touched.add(i)
+        kind = j % 5
+        if kind == 0:
+            pkb[48 * i:48 * i + 48] = bad_pk[j % 3]
+        elif kind == 1:
+            sgb[96 * i:96 * i + 96] = bad_sg[j % 3]
+        elif kind == 2:
+            pkb[48 * i:48 * i + 48] = bytes([0xc0]) + bytes(47)                 # infinity key
+        elif kind == 3:
+            pkb[48 * i] &= 0x7f                                                 # compression bit cleared
+        else:
+            sgb[96 * i:96 * i + 96] = BAD_SIG
+    okc, outc, stc = co.deserialize_sets(bytes(pkb), ms, bytes(sgb))
+    ok, out, st = m.deserializeSets(cache, bytes(pkb), ms, bytes(sgb))
+    assert (ok, st) == (okc, stc) and not ok
+    assert all(st[i] != 0 for i in touched) and sum(1 for x in st if x) == len(touched)
+    good = [i for i in range(n) if st[i] == 0]
+    assert all(out[320 * i:320 * i + 320] == outc[320 * i:320 * i + 320] for i in good)
+    assert all(out[320 * i:320 * i + 320] == rec[320 * i:320 * i + 320] for i in good[::97])
+    cache.close()

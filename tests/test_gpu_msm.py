@@ -123,3 +123,96 @@ def test_msm_linearity_at_2_20(m, cache):
     b = g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts, k2.tobytes(), 255))
     c = g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts, s.tobytes(), 255))
     assert o.g1_add(a, b) == c and c is not None
+
+
+def _bench_points(n, seed, distinct=4096):
+    import c_oracle as co
+    rng = random.Random(seed)
+    base = [co.sk_to_pk(rng.getrandbits(96) | 1) for _ in range(distinct)]
+    return b"".join(base[i % distinct] for i in range(n))
+
+
+def test_msm_config4_vs_c_oracle_at_2_20(m, cache):
+    """BASELINE config 4 at its own size: 2^20 points x 255-bit scalars (16 windows of 16 bits, 2^15 buckets, 32 sort slices, two
+    window groups on two streams) against the C restatement of the bucket method (oracle_msm_g1_pippenger, OpenMP over the
+    windows), through the host-array entry and the device-resident one."""
+    import c_oracle as co
+    import numpy as np
+    import torch
+    n = 1 << 20
+    pts = _bench_points(n, 2020)
+    sc = np.random.default_rng(2020).integers(0, 256, size=(n, 32), dtype=np.uint8).tobytes()
+    want = co.msm_g1_pippenger(pts, sc, 255)
+    got = m.p1s_mult_pippenger(cache, pts, sc, 255)
+    assert o.g1_to_blst_affine(g1_jac_to_affine(got)) == want
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    got = m.p1s_mult_pippenger_device(cache, dp.data_ptr(), n, ds.data_ptr(), 255)
+    print("msm 2^20 timings(ms):", cache.timings())
+    assert o.g1_to_blst_affine(g1_jac_to_affine(got)) == want
+
+
+@pytest.mark.parametrize("ngpu", [1, 2, 3, 8])
+def test_msm_multi_equals_c_oracle_at_2_17(m, ngpu):
+    """Point-sharded MSM over ngpu contexts (several contexts on ONE device stand in for several devices): 2^17 + 5 points (ragged
+    shards) x 255 bits == the C restatement; empty input and fewer points than devices."""
+    import c_oracle as co
+    import numpy as np
+    n = (1 << 17) + 5
+    pts = _bench_points(n, 17)
+    sc = np.random.default_rng(17).integers(0, 256, size=(n, 32), dtype=np.uint8).tobytes()
+    want = co.msm_g1_pippenger(pts, sc, 255)
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=64) for _ in range(ngpu)]
+    got = m.p1s_mult_pippenger_multi(caches, pts, sc, 255)
+    assert o.g1_to_blst_affine(g1_jac_to_affine(got)) == want
+    assert m.p1s_mult_pippenger_multi(caches, b"", b"", 255) == bytes(144)
+    small = m.p1s_mult_pippenger_multi(caches, pts[:96 * 3], sc[:32 * 3], 255)           # 3 points: some devices get none
+    assert o.g1_to_blst_affine(g1_jac_to_affine(small)) == co.msm_g1(pts[:96 * 3], sc[:32 * 3], 255)
+    covered = 0
+    for g in range(ngpu):
+        first, count = m.msm_shard_range(n, ngpu, g)
+        assert first == covered
+        covered += count
+    assert covered == n
+    for c in caches:
+        c.close()
+
+
+def test_msm_multi_at_2_20_and_partial_merge(m, cache):
+    """2^20 points: 8 shards == the single-device result == the C restatement; the one-process-per-GPU form (every rank's partial
+    left in device memory, p1s_add_device on the gathered partials) and the host merge (p1s_add) agree; G2 shards likewise."""
+    import c_oracle as co
+    import numpy as np
+    import torch
+    from util import g2_jac_to_affine
+    n = 1 << 20
+    pts = _bench_points(n, 2020)
+    sc = np.random.default_rng(2020).integers(0, 256, size=(n, 32), dtype=np.uint8).tobytes()
+    single = g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts, sc, 255))
+    assert o.g1_to_blst_affine(single) == co.msm_g1_pippenger(pts, sc, 255)
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=64) for _ in range(8)]
+    assert g1_jac_to_affine(m.p1s_mult_pippenger_multi(caches, pts, sc, 255)) == single
+    # device-resident shards + the rank-style flow
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    ranges = [m.msm_shard_range(n, 8, g) for g in range(8)]
+    got = m.p1s_mult_pippenger_multi_device(caches, [dp.data_ptr() + 96 * f for f, c in ranges], n, [ds.data_ptr() + 32 * f for f, c in ranges], 255)
+    assert g1_jac_to_affine(got) == single
+    gathered = torch.zeros(8 * 256, dtype=torch.uint8, device="cuda")                   # 8 partials, 256 bytes apart
+    for g, (f, c) in enumerate(ranges):
+        m.p1s_mult_pippenger_partial_device(caches[g], gathered.data_ptr() + 256 * g, dp.data_ptr() + 96 * f, c, ds.data_ptr() + 32 * f, 255)
+    torch.cuda.synchronize()
+    assert g1_jac_to_affine(m.p1s_add_device(caches[0], gathered.data_ptr(), 8, 256)) == single
+    parts = bytes(gathered.cpu().numpy())
+    assert g1_jac_to_affine(m.p1s_add(caches[0], [parts[256 * g:256 * g + 144] for g in range(8)])) == single
+    assert g1_jac_to_affine(m.p1s_add(caches[0], [bytes(144), parts[:144], bytes(144)])) == g1_jac_to_affine(parts[:144])     # infinity partials
+    # G2: 3 shards of 5000 points x 64-bit scalars (combine's shape)
+    rng = random.Random(5)
+    h = co.hash_to_g2(b"g2 multi", o.DST_SIG)
+    base = [co.g2_mul(h, rng.randrange(1, o.R)) for _ in range(64)]
+    q = b"".join(base[i % 64] for i in range(5000))
+    k = b"".join(rng.getrandbits(64).to_bytes(32, "little") for _ in range(5000))
+    got2 = m.p1s_mult_pippenger_multi(caches[:3], q, k, 64, g2=True)
+    assert o.g2_to_blst_affine(g2_jac_to_affine(got2)) == co.msm_g2(q, k, 64, 32)
+    for c in caches:
+        c.close()

@@ -72,8 +72,8 @@ def test_verify_multi_equals_whole_batch(m):
     ptrs = [t.data_ptr() + 320 * m.shard_plan(n, nt, 4, g)[2] for g in range(4)]
     assert m.batchVerifyMulti_device(caches, ptrs, n, RND) is True
     assert caches[0].fetch(4, 576) == gt
-    with pytest.raises(m.BlsGpuError):                           # a shard larger than its context: loud
-        m.batchVerifyMulti(caches[:2], rec, RND)
+    assert m.batchVerifyMulti(caches[:2], rec, RND) is True      # a shard larger than its context (500 > 300): sliced inside the library
+    assert caches[0].fetch(4, 576) == gt
     for c in caches + [whole]:
         c.close()
 

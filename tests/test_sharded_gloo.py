@@ -117,3 +117,78 @@ def test_shard_plan_partitions():
                 assert first == chunks[lo][0] and count == sum(c[1] for c in chunks[lo:hi])
             nxt_c, nxt_t = hi, first + count
         assert nxt_t == n
+
+
+def _msm_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    import bls12381_py as o
+    from util import golden, g1_aff_to_jac_bytes, g1_jac_to_affine
+    spec = importlib.util.spec_from_file_location("nim_blscurve_amd.sharded", os.path.join(ROOT, "nim-blscurve_amd", "sharded.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    v = [x for x in golden("msm")["msm"] if x["n"] >= n][0]
+    pts, sc = bytes.fromhex(v["points"])[:96 * n], bytes.fromhex(v["scalars"])[:32 * n]
+    P = [o.g1_from_blst_affine(pts[96 * i:96 * i + 96]) for i in range(n)]
+    K = [int.from_bytes(sc[32 * i:32 * i + 32], "little") for i in range(n)]
+
+    def local_partial(first, count):          # oracle stand-in for mi355_bls_p1s_mult_pippenger_partial_device
+        return g1_aff_to_jac_bytes(o.msm_g1(P[first:first + count], K[first:first + count], 255))
+
+    def add_partials(parts):                  # oracle stand-in for mi355_bls_p1s_add
+        acc = None
+        for b in parts:
+            acc = o.g1_add(acc, g1_jac_to_affine(b))
+        return g1_aff_to_jac_bytes(acc)
+
+    def all_gather(blob):
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [bytes(x.numpy().tobytes()) for x in out]
+
+    res = sh.msm_sharded(local_partial, add_partials, n, rank, world, all_gather)
+    if rank == 0:
+        q.put(g1_jac_to_affine(res) == o.msm_g1(P, K, 255))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 31])
+def test_msm_two_process_gloo(n):
+    """Point-sharded MSM protocol over gloo, world_size 2: shard ranges, one 144-byte all_gather, merge on rank 0 (oracle arithmetic
+    standing in for the device entry points); n = 1 leaves rank 1 with an empty shard."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + n
+    procs = [ctx.Process(target=_msm_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_msm_shard_range_matches_the_library():
+    """The python mirror of the MSM shard plan == mi355_bls_msm_shard_range (a host function: no GPU needed)."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import __graft_entry__ as ge
+    m = ge.load_package()
+    spec = importlib.util.spec_from_file_location("sharded", os.path.join(ROOT, "nim-blscurve_amd", "sharded.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    for n, w in [(1 << 20, 8), (7, 8), (0, 3), (100, 3), ((1 << 17) + 5, 5)]:
+        covered = 0
+        for r in range(w):
+            assert sh.msm_shard_range(n, w, r) == m.msm_shard_range(n, w, r)
+            f, c = sh.msm_shard_range(n, w, r)
+            assert f == covered
+            covered += c
+        assert covered == n
