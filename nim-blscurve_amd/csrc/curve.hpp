@@ -197,10 +197,10 @@ BLS_MID xyzz<F> xyzz_dbl_aff(const aff<F>& q) {          // q not at infinity
     r.zzz = W;
     return r;
 }
+// q_inf: "q is the point at infinity", known to the caller (xyzz_add_aff tests the coordinates)
 template <class F>
-BLS_MID xyzz<F> xyzz_add_aff(const xyzz<F>& p, const aff<F>& q) {
+BLS_MID xyzz<F> xyzz_add_aff_flag(const xyzz<F>& p, const aff<F>& q, bool q_inf) {
     bool p_inf = f_is_zero(p.zz);
-    bool q_inf = aff_is_inf(q);
     F U2 = f_mul(q.x, p.zz);
     F S2 = f_mul(q.y, p.zzz);
     F P = f_sub(U2, p.x);
@@ -220,6 +220,8 @@ BLS_MID xyzz<F> xyzz_add_aff(const xyzz<F>& p, const aff<F>& q) {
     r = xyzz_select(p_inf, xyzz<F>{q.x, q.y, one_or_zero, one_or_zero}, r);
     return r;
 }
+template <class F>
+BLS_MID xyzz<F> xyzz_add_aff(const xyzz<F>& p, const aff<F>& q) { return xyzz_add_aff_flag(p, q, aff_is_inf(q)); }
 template <class F>
 BLS_MID jac<F> jac_from_xyzz(const xyzz<F>& p) { return jac<F>{f_mul(p.x, p.zz), f_mul(p.y, p.zzz), p.zz}; }
 

@@ -1162,7 +1162,9 @@ __global__ void __launch_bounds__(WAVE) k_pip_convert(const uint8_t* __restrict_
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     if (i >= n) return;
     aff<F> q = ld_aff_blst(reinterpret_cast<const uint32_t*>(pts + (size_t)i * fld<F>::AFFB), (const aff<F>*)nullptr);
-    st_aff_int(pts_int + (size_t)i * 2 * fld<F>::W, q);
+    uint32_t* o = pts_int + (size_t)i * 2 * fld<F>::W;
+    st_aff_int(o, q);
+    o[FP_N] = aff_is_inf(q) ? 1u : 0u;                  // first pad word of x: "this point is the point at infinity" (tested once here, not per bucket addition)
 }
 // lane per (window, bucket); `order` lists the buckets so that a wave's lanes have similar counts
 template <class F>
@@ -1176,11 +1178,22 @@ __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_b
     uint32_t w = g >> cbk, cnt = hist[g], off = offs[g];
     const uint32_t* srt = sorted + (size_t)w * n + off;
     xyzz<F> acc = xyzz_inf<F>();                        // extended Jacobian: 8M + 2S per mixed addition (curve.hpp)
-    for (uint32_t j = 0; j < cnt; j++) {
-        uint32_t e = srt[j];
-        aff<F> q = ld_aff_int(pts + (size_t)(e & 0x7fffffffu) * (2 * fld<F>::W), (const aff<F>*)nullptr);
+    // the first point of a bucket initialises the accumulator (no addition: 3 % of all additions at 32 points per bucket); the
+    // "operand is the point at infinity" test was made once by k_pip_convert
+    if (cnt) {
+        uint32_t e = srt[0];
+        const uint32_t* pw = pts + (size_t)(e & 0x7fffffffu) * (2 * fld<F>::W);
+        aff<F> q = ld_aff_int(pw, (const aff<F>*)nullptr);
         if (e >> 31) q.y = f_neg(q.y);
-        acc = xyzz_add_aff(acc, q);
+        F one_or_zero = f_select(pw[FP_N] != 0, f_zero<F>(), f_one<F>());
+        acc = xyzz<F>{q.x, q.y, one_or_zero, one_or_zero};
+    }
+    for (uint32_t j = 1; j < cnt; j++) {
+        uint32_t e = srt[j];
+        const uint32_t* pw = pts + (size_t)(e & 0x7fffffffu) * (2 * fld<F>::W);
+        aff<F> q = ld_aff_int(pw, (const aff<F>*)nullptr);
+        if (e >> 31) q.y = f_neg(q.y);
+        acc = xyzz_add_aff_flag(acc, q, pw[FP_N] != 0);
     }
     soa_st_jac(buckets, total, g, jac_from_xyzz(acc));
 }
@@ -1328,7 +1341,7 @@ __global__ void __launch_bounds__(WAVE) k_sig_consts(uint32_t c, uint32_t total,
 // then the L partial sums are folded with wave shuffles.  Result -> Miller pair n + g = (consts[g], B_g).
 __global__ void __launch_bounds__(WAVE) k_sig_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
                                                      const uint32_t* __restrict__ hist, uint32_t n, uint32_t c, uint32_t lshift, uint32_t total,
-                                                     const uint32_t* __restrict__ consts, uint4* __restrict__ H, uint4* __restrict__ P, size_t stride) {
+                                                     const uint32_t* __restrict__ consts, uint4* __restrict__ H, uint4* __restrict__ P, size_t stride, size_t base) {
     uint32_t t = blockIdx.x * WAVE + threadIdx.x;
     uint32_t L = 1u << lshift, g = t >> lshift, s = t & (L - 1);
     xyzz<fp2> part = xyzz_inf<fp2>();                   // extended Jacobian: 8M + 2S per mixed addition (curve.hpp)
@@ -1347,8 +1360,8 @@ __global__ void __launch_bounds__(WAVE) k_sig_bucket(const uint32_t* __restrict_
         acc = jac_add(acc, o);
     }
     if (g < total && s == 0) {
-        soa_st_g2(H, stride, (size_t)n + g, acc);
-        soa_st_g1(P, stride, (size_t)n + g, ld_g1_int(consts + (size_t)g * G1W));
+        soa_st_g2(H, stride, base + g, acc);
+        soa_st_g1(P, stride, base + g, ld_g1_int(consts + (size_t)g * G1W));
     }
 }
 // On demand (fetch_stage 3): sum [r_i]S_i = sum_w 2^(cw) sum_d d B_{w,d}; lane w folds window w with running
@@ -1604,6 +1617,7 @@ struct mi355_bls_ctx {
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
     hipEvent_t ev_hm = nullptr, ev_lp = nullptr;   // inside the hash stage (after k_hash_map) and the line-product stage (after k_lineprod)
+    hipEvent_t ev_s0 = nullptr, ev_l0 = nullptr;   // start of the signature side (on its stream) and of the tuple pairs' Miller lines: the stage timers of forked calls
     float ktimes[4] = {};         // k_hash_map, k_hash_clear, k_lineprod, k_lineprod2 of the last batch call
     uint32_t slots = 1024;        // wave slots at one wave per SIMD: 4 x CUs
     size_t last_n = 0;
@@ -1638,6 +1652,8 @@ extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_hm) (void)hipEventDestroy(c->ev_hm);
     if (c->ev_lp) (void)hipEventDestroy(c->ev_lp);
+    if (c->ev_s0) (void)hipEventDestroy(c->ev_s0);
+    if (c->ev_l0) (void)hipEventDestroy(c->ev_l0);
     if (c->ev_deser0) (void)hipEventDestroy(c->ev_deser0);
     if (c->ev_deser1) (void)hipEventDestroy(c->ev_deser1);
     if (c->msm2) {
@@ -1681,7 +1697,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_M, c->mstride * 6 * 64);
     ALLOC(c->d_P, c->stride * 3 * 64);
     ALLOC(c->d_lines, c->stride * 6 * 64 * (size_t)N_LINES);
-    ALLOC(c->d_spart, (nwaves + 16) * G2W * 4);
+    ALLOC(c->d_spart, 1024);
     ALLOC(c->d_sig_pts, max_sets * 4 * FPW * 4);
     ALLOC(c->d_sig_sorted, max_sets * 16 * 4);
     ALLOC(c->d_sig_hist, 3 * SIG_SLOTS_MAX * 4);
@@ -1707,6 +1723,8 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreate(&c->ev_hm));
     HIPCHK(hipEventCreate(&c->ev_lp));
+    HIPCHK(hipEventCreate(&c->ev_s0));
+    HIPCHK(hipEventCreate(&c->ev_l0));
     HIPCHK(hipEventCreate(&c->ev_deser0));
     HIPCHK(hipEventCreate(&c->ev_deser1));
     k_sig_consts<<<(256 + WAVE - 1) / WAVE, WAVE>>>(4, 256, c->d_sig_consts);
@@ -1879,7 +1897,11 @@ static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     const bool fork = c->coop && c->side && n32 <= 16 * c->slots;       // pk + signature side beside the hashing
     // A whole-chip batch of ONE caller (latency mode): the signature side and the Miller lines of its extra pairs run on the side
     // stream beside the hashing.  The tuple pairs then fill the chip's wave slots exactly once; behind them the extra pairs
-    // would be a second round of waves (or ~1 ms of the 8-lanes-per-pair kernel).
+    // would be a second round of waves (or ~1 ms of the 8-lanes-per-pair kernel).  Throughput mode keeps everything on the
+    // caller's stream: with several batches in flight the nearly empty second round overlaps other batches' kernels, and
+    // folding the 2048 bucket sums further (to 64 per-bit sums, or to one sum per window) so that fewer extra pairs remain was
+    // measured SLOWER per pipelined batch (+0.5 ms and +2.5 ms: the fold is a chain of small dependent kernels on the batch's
+    // critical path, the 2048 extra pairs are 3 % more of two embarrassingly parallel kernels).
     const bool fork_sig = !fork && c->coop && c->side;
     hipStream_t sd = fork ? c->side : st;                               // [r]PK
     hipStream_t ss = (fork || fork_sig) ? c->side : st;                 // signature side
@@ -1902,6 +1924,7 @@ static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     {
         msm_win W{nwin, cw, 0};
         uint32_t *hist = c->d_sig_hist, *offs = hist + SIG_SLOTS_MAX, *cursor = offs + SIG_SLOTS_MAX;
+        HIPCHK(hipEventRecord(c->ev_s0, ss));
         HIPCHK(hipMemsetAsync(hist, 0, (size_t)total * 4, ss));
         k_sig_convert<<<nb, WAVE, 0, ss>>>(d_sets, n32, c->d_sig_pts);
         k_msm_hist<<<dim3(nb, nwin), WAVE, 0, ss>>>(reinterpret_cast<const uint8_t*>(c->d_r), 8, n32, W, cw, hist);
@@ -1914,7 +1937,7 @@ static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         while (lshift < 6 && ((total << (lshift + 1)) <= 16 * c->slots) && (per >> (lshift + 1)) >= 2) lshift++;
         k_sig_bucket<<<((total << lshift) + WAVE - 1) / WAVE, WAVE, 0, ss>>>(c->d_sig_pts, c->d_sig_sorted, offs, hist, n32, cw, lshift, total,
                                                                              c->d_sig_consts + (cw == 8 ? (size_t)SIG_SLOTS_MAX * G1W : 0), c->d_H, c->d_P,
-                                                                             c->stride);
+                                                                             c->stride, (size_t)n32);
         c->sig_c = cw;
         c->sig_slots = total;
         c->agg_valid = false;
@@ -1924,11 +1947,13 @@ static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
     if (fork_sig) {
         k_lines<<<(total + WAVE - 1) / WAVE, WAVE, 0, ss>>>(c->d_P, c->d_H, n32, total, c->stride, c->d_lines);
         HIPCHK(hipEventRecord(c->ev[4], ss));
+        HIPCHK(hipEventRecord(c->ev_l0, st));
         launch_lines(c, n32, 0, st);
         HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));                    // join
     } else {
         HIPCHK(hipEventRecord(c->ev[4], ss));
         if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev[4], 0));          // join
+        HIPCHK(hipEventRecord(c->ev_l0, st));
         launch_lines(c, npairs, total, st);
     }
     HIPCHK(hipEventRecord(c->ev[5], st));
@@ -2008,6 +2033,10 @@ static int collect_timings(mi355_bls_ctx* c, int last_ev) {
     for (int i = 0; i < last_ev; i++) {
         HIPCHK(hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]));
         if (c->timings[i] < 0) c->timings[i] = 0;              // stages that ran side by side on the fork stream
+    }
+    if (last_ev == 7) {                           // batch path: the signature side and the lines by their own start events (forked calls)
+        HIPCHK(hipEventElapsedTime(&c->timings[3], c->ev_s0, c->ev[4]));
+        HIPCHK(hipEventElapsedTime(&c->timings[4], c->ev_l0, c->ev[5]));
     }
     HIPCHK(hipEventElapsedTime(&c->timings[7], c->ev[0], c->ev[last_ev]));
     return 0;
@@ -2615,14 +2644,19 @@ static int msm_enqueue(mi355_bls_ctx* c, msm_ws* m, const void* d_points, size_t
         ngroups = 2;
     }
     // group g runs on its own stream, its bucket kernel behind the bucket kernel of group g - 1: the (latency-bound, few-wave)
-    // reduction of a group is dispatched before the next group's bucket kernel and runs beside it
+    // reduction of a group is dispatched before the next group's bucket kernel and runs beside it.  (Both bucket kernels enqueued at
+    // once, the second on a lowest-priority stream so that its waves would only fill the tail of the first - 26 % of a bucket
+    // kernel's wave slots idle on average, profiles/r03_pmc_summary_msm.json - was measured 3 % SLOWER: the 512-register reduction
+    // waves of the first group then wait for whole SIMDs that the second group's 256-register waves keep half full.)
     hipStream_t gs[2] = {st, c->side};
+    const bool chain = true;
     hipEvent_t gev[2] = {m->ev_fork, m->ev_bucketed};
     count_sort(0, nw, st);
     for (uint32_t g = 0; g < ngroups; g++) order_group(cut[g + 1], cut[g], g, st);
     if (timed) HIPCHK(hipEventRecord(c->ev[1], st));
+    if (ngroups > 1) HIPCHK(hipEventRecord(m->ev_join, st));       // sorted: the other group's stream may start
     for (uint32_t g = 0; g < ngroups; g++) {
-        if (g) HIPCHK(hipStreamWaitEvent(gs[g], gev[g - 1], 0));
+        if (g) HIPCHK(hipStreamWaitEvent(gs[g], chain ? gev[g - 1] : m->ev_join, 0));
         bucket_group(cut[g + 1], cut[g], gs[g]);
         HIPCHK(hipEventRecord(gev[g], gs[g]));
         if (g == 0 && timed) HIPCHK(hipEventRecord(c->ev[2], st));

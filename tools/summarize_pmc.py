@@ -17,6 +17,9 @@ try:
 except Exception:                      # torch missing: the shares are simply not computed
     KERNEL_BYTES, MAD_PER_TUPLE = {}, {}
 TUPLES = 65536
+# multiply-adds per LAUNCH of the Pippenger kernels at 2^20 points x 255 bits (tests/gpu_probe_aux.py msm): k_pip_bucket runs once per
+# group of 8 windows, one mixed addition (8M + 2S = 3738 multiply-adds) per (point, window) with a non-zero digit
+MSM_MAD_PER_LAUNCH = {"k_pip_bucket": (1 << 20) * 8 * (1 - 2.0 ** -16) * 3738}
 out, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -37,6 +40,10 @@ for k, v in agg.items():
         e["hbm_bytes_corrected"] = 2 * f + w
     if "SQ_WAVE_CYCLES" in e and e.get("SQ_INSTS_VALU"):
         e["cycles_per_valu"] = 4 * e["SQ_WAVE_CYCLES"] / e["SQ_INSTS_VALU"]
+    if e.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in e:
+        e["wait_any_share"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+    if e.get("SQ_INSTS_VALU") and k in MSM_MAD_PER_LAUNCH:
+        e["mad_share_of_valu"] = MSM_MAD_PER_LAUNCH[k] / 64.0 / e["SQ_INSTS_VALU"]
     if e.get("SQ_INSTS_VALU") and k in MAD_PER_TUPLE:
         # 64-bit multiply-adds (census of the formulas, bench.py MAD_PER_TUPLE) as a share of all VALU wave-instructions:
         # one wave-instruction serves 64 tuples (k_hash_map: two lanes per tuple, so 32)
