@@ -1566,7 +1566,8 @@ static void msm_free(msm_ws* m) {
 
 struct mi355_bls_ctx {
     int device = 0;
-    size_t cap = 0;          // max sets
+    size_t cap = 0;          // sets the pipeline workspace holds at once (larger batches are sliced)
+    size_t cap_io = 0;       // sets the staging buffers d_sets / d_comp / d_status / d_r hold (>= cap; grown on demand, io_reserve)
     size_t stride = 0;       // pairs capacity (cap + 1 rounded up to 64)
     uint32_t num_threads = 4096;
     uint32_t nblk_cap = 64;
@@ -1673,6 +1674,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     c->msm = new msm_ws();
     c->msm2 = new msm_ws();
     c->cap = max_sets;
+    c->cap_io = max_sets;
     c->stride = ((max_sets + 1 + SIG_SLOTS_MAX + 63) / 64) * 64;          // tuple pairs + the extra pair(s) of the signature side
     std::memset(&c->dst, 0, sizeof(c->dst));
     c->dst.len = sizeof(DST_SIG) - 1;
@@ -1753,6 +1755,32 @@ extern "C" int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_
         return rc;
     }
     *out = c;
+    return 0;
+}
+
+// The staging buffers of the entry points around the batch path (wire-format arrays, keys of fastAggregateVerify, the records
+// fromBytes writes, combine's inputs and scalars) grow on demand: like the reference's procs, which take any openArray, no entry
+// point refuses an input for its size.  (The pipeline workspace itself stays at max_sets: larger batches are sliced, run_shard.)
+static int io_reserve(mi355_bls_ctx* c, size_t n) {
+    if (n <= c->cap_io) return 0;
+    if (c->pending) {
+        g_err = "a batch submitted on this context has not been waited for";
+        return MI355_BLS_ERR_ARG;
+    }
+    size_t want = n + n / 4;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    void** bufs[] = {(void**)&c->d_sets, (void**)&c->d_comp, (void**)&c->d_status, (void**)&c->d_r};
+    for (void** b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    c->cap_io = 0;
+    HIPCHK(hipMalloc((void**)&c->d_sets, want * 320));
+    HIPCHK(hipMalloc((void**)&c->d_comp, want * 320));
+    HIPCHK(hipMalloc((void**)&c->d_status, want));
+    HIPCHK(hipMalloc((void**)&c->d_r, (want > c->stride ? want : c->stride) * 8));
+    c->cap_io = want;
     return 0;
 }
 
@@ -2447,7 +2475,10 @@ extern "C" int mi355_bls_g1_aggregate_device(mi355_bls_ctx* c, const void* d_pks
 
 extern "C" int mi355_bls_g1_aggregate(mi355_bls_ctx* c, const void* pks, size_t n, uint8_t out_p1[144]) {
     if (!c || !pks || !out_p1 || n == 0) return MI355_BLS_ERR_ARG;
-    if (n * 96 > c->cap * 320) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, (n * 96 + 319) / 320);
+        if (rcr) return rcr;
+    }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_sets, pks, n * 96, hipMemcpyHostToDevice, nullptr));
     return mi355_bls_g1_aggregate_device(c, c->d_sets, n, nullptr, out_p1);
@@ -2495,7 +2526,10 @@ extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks
     if (!c) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;
     if (!pks) return MI355_BLS_ERR_ARG;
-    if (n * 96 > c->cap * 320) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, (n * 96 + 319) / 320);
+        if (rcr) return rcr;
+    }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_sets, pks, n * 96, hipMemcpyHostToDevice, nullptr));
     return mi355_bls_fast_aggregate_verify_device(c, c->d_sets, n, msg, msg_len, sig, nullptr);
@@ -2805,7 +2839,10 @@ extern "C" void mi355_p2s_mult_pippenger(void* ret, const void* const points[], 
 // Wire-format entry points: batched fromBytes (+ batchVerify)
 // ------------------------------------------------------------------------------------------
 static int deser_enqueue(mi355_bls_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint8_t* d_sigs, size_t n, uint32_t dflags, hipStream_t st) {
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, n);
+        if (rcr) return rcr;
+    }
     if (dflags > 7) return MI355_BLS_ERR_ARG;
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
     k_deser<<<((uint32_t)n + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_pks, d_msgs, d_sigs, (uint32_t)n, dflags, c->d_sets, c->d_status, c->d_flags);
@@ -2837,11 +2874,14 @@ extern "C" int mi355_bls_deserialize_sets_ex_device(mi355_bls_ctx* c, const void
 
 // host wire-format arrays -> d_comp: keys at 0, messages at cap * 96, signatures at cap * 128
 static int stage_compressed(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint8_t* sigs, size_t n, uint32_t dflags) {
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, n);
+        if (rcr) return rcr;
+    }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_comp, pks, n * ((dflags & DESER_F_PK_UNCOMPRESSED) ? 96 : 48), hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 96, msgs, n * 32, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 128, sigs, n * ((dflags & DESER_F_SIG_UNCOMPRESSED) ? 192 : 96), hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap_io * 96, msgs, n * 32, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap_io * 128, sigs, n * ((dflags & DESER_F_SIG_UNCOMPRESSED) ? 192 : 96), hipMemcpyHostToDevice, nullptr));
     return 0;
 }
 extern "C" int mi355_bls_deserialize_sets_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n, void* stream,
@@ -2855,7 +2895,7 @@ extern "C" int mi355_bls_deserialize_sets_ex(mi355_bls_ctx* c, const uint8_t* pk
     if (!pks || !msgs32 || !sigs) return MI355_BLS_ERR_ARG;
     int rc = stage_compressed(c, pks, msgs32, sigs, n, dflags);
     if (rc) return rc;
-    return mi355_bls_deserialize_sets_ex_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, dflags, nullptr, out_sets, status);
+    return mi355_bls_deserialize_sets_ex_device(c, c->d_comp, c->d_comp + c->cap_io * 96, c->d_comp + c->cap_io * 128, n, dflags, nullptr, out_sets, status);
 }
 
 extern "C" int mi355_bls_deserialize_sets(mi355_bls_ctx* c, const uint8_t* pks48, const uint8_t* msgs32, const uint8_t* sigs96, size_t n, void* out_sets,
@@ -2865,7 +2905,7 @@ extern "C" int mi355_bls_deserialize_sets(mi355_bls_ctx* c, const uint8_t* pks48
     if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
     int rc = stage_compressed(c, pks48, msgs32, sigs96, n, 0);
     if (rc) return rc;
-    return mi355_bls_deserialize_sets_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, nullptr, out_sets, status);
+    return mi355_bls_deserialize_sets_device(c, c->d_comp, c->d_comp + c->cap_io * 96, c->d_comp + c->cap_io * 128, n, nullptr, out_sets, status);
 }
 
 extern "C" int mi355_bls_batch_verify_compressed_device(mi355_bls_ctx* c, const void* d_pks48, const void* d_msgs32, const void* d_sigs96, size_t n,
@@ -2895,7 +2935,7 @@ extern "C" int mi355_bls_batch_verify_compressed(mi355_bls_ctx* c, const uint8_t
     if (!pks48 || !msgs32 || !sigs96) return MI355_BLS_ERR_ARG;
     int rc = stage_compressed(c, pks48, msgs32, sigs96, n, 0);
     if (rc) return rc;
-    return mi355_bls_batch_verify_compressed_device(c, c->d_comp, c->d_comp + c->cap * 96, c->d_comp + c->cap * 128, n, rnd, nullptr, status);
+    return mi355_bls_batch_verify_compressed_device(c, c->d_comp, c->d_comp + c->cap_io * 96, c->d_comp + c->cap_io * 128, n, rnd, nullptr, status);
 }
 
 extern "C" float mi355_bls_last_deser_ms(mi355_bls_ctx* c) { return c ? c->deser_ms : 0.f; }
@@ -2908,7 +2948,10 @@ extern "C" int mi355_bls_sign_sets_device(mi355_bls_ctx* c, const void* d_sks32,
     if (!c) return MI355_BLS_ERR_ARG;
     if (n == 0) return 1;
     if (!d_sks32 || !d_msgs32 || !d_out_sets) return MI355_BLS_ERR_ARG;
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, n);
+        if (rcr) return rcr;
+    }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
@@ -2932,11 +2975,14 @@ extern "C" int mi355_bls_sign_sets(mi355_bls_ctx* c, const uint8_t* sks32, const
     if (!c) return MI355_BLS_ERR_ARG;
     if (n == 0) return 1;
     if (!sks32 || !msgs32 || !out_sets) return MI355_BLS_ERR_ARG;
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, n);
+        if (rcr) return rcr;
+    }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_comp, sks32, n * 32, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap * 48, msgs32, n * 32, hipMemcpyHostToDevice, nullptr));
-    int rc = mi355_bls_sign_sets_device(c, c->d_comp, c->d_comp + c->cap * 48, n, c->d_sets, nullptr, status);
+    HIPCHK(hipMemcpyAsync(c->d_comp + c->cap_io * 48, msgs32, n * 32, hipMemcpyHostToDevice, nullptr));
+    int rc = mi355_bls_sign_sets_device(c, c->d_comp, c->d_comp + c->cap_io * 48, n, c->d_sets, nullptr, status);
     if (rc < 0) return rc;
     HIPCHK(hipMemcpy(out_sets, c->d_sets, n * 320, hipMemcpyDeviceToHost));
     HIPCHK(hipMemsetAsync(c->d_comp, 0, n * 32, nullptr));          // do not leave the scalars in the staging buffer
@@ -2954,7 +3000,10 @@ extern "C" int mi355_bls_combine(mi355_bls_ctx* c, const uint8_t rnd[32], const 
         memcpy(out_sig, sigs, 192);
         return 0;
     }
-    if (n > c->cap) return MI355_BLS_ERR_CAPACITY;
+    {
+        int rcr = io_reserve(c, n);
+        if (rcr) return rcr;
+    }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = nullptr;
     uint8_t* d_pk = c->d_sets;                    // staging: n x 96 then n x 192 (<= n x 320)

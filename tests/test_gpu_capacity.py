@@ -127,3 +127,47 @@ def test_multi_driver_survives_an_enqueue_failure(m):
     assert k == 3 and us[0] <= us[1] <= us[2]
     for c in caches:
         c.close()
+
+
+def test_staging_grows_for_the_entry_points_around_the_path(m):
+    """A context sized for 64 sets takes 500-tuple inputs through every other entry point (their staging buffers grow on demand):
+    fromBytes, the wire-format batch verify (growth + slices), the batch signer, combine, fastAggregateVerify - same results as a
+    context sized for the input."""
+    import c_oracle as co
+    import bls12381_py as o
+    n = 500
+    rec = co.make_batch(n, seed=424242)
+    pk, ms, sg = co.compress_sets(rec)
+    small = m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=16)
+    ok, out, st = m.deserializeSets(small, pk, ms, sg)
+    assert ok and out == rec and st == bytes(n)
+    v, st = m.batchVerifyCompressed(small, pk, ms, sg, RND)
+    assert v is True and st == bytes(n)
+    okc, stc = co.batch_verify(rec, RND, 16, stages=True)
+    assert okc and small.fetch(4, 576) == stc["gt"]
+    sgb = bytearray(sg)
+    sgb[96 * 400:96 * 401], sgb[96 * 401:96 * 402] = sg[96 * 401:96 * 402], sg[96 * 400:96 * 401]
+    v, st = m.batchVerifyCompressed(small, pk, ms, bytes(sgb), RND)
+    assert v is False and st == bytes(n)
+    # batch signer: the records of a big-enough context
+    import hashlib
+    sks = [(int.from_bytes(hashlib.sha256(b"grow" + bytes([i % 256, i // 256])).digest(), "little") % (o.R - 1) + 1).to_bytes(32, "little") for i in range(200)]
+    msgs = [hashlib.sha256(b"m" + bytes([i % 256])).digest() for i in range(200)]
+    big = m.BatchedBLSVerifierCache.init(max_sets=512, numThreads=16)
+    small2 = m.BatchedBLSVerifierCache.init(max_sets=8)
+    assert m.signSets(small2, sks, msgs) == m.signSets(big, sks, msgs)
+    # combine of 300 signatures on one message; fastAggregateVerify of 300 keys
+    same, sksum = [], 0
+    msg = hashlib.sha256(b"Mr F was here").digest()
+    okg, same_rec, _ = m.signSets(big, sks, [msg] * 200)
+    assert okg
+    pks = [same_rec[320 * i:320 * i + 96] for i in range(200)]
+    sigs = [same_rec[320 * i + 128:320 * i + 320] for i in range(200)]
+    tiny = m.BatchedBLSVerifierCache.init(max_sets=4)
+    assert m.MultiSignatureSet.init(pks, msg, sigs).combine(tiny, RND) == m.MultiSignatureSet.init(pks, msg, sigs).combine(big, RND)
+    agg = co.g2_sum(b"".join(sigs))
+    assert co.fast_aggregate_verify(b"".join(pks), msg, agg) is True
+    assert m.fastAggregateVerify(tiny, pks, msg, agg) is True
+    assert m.fastAggregateVerify(tiny, pks[:-1], msg, agg) is False
+    for c in (small, small2, big, tiny):
+        c.close()
