@@ -10,12 +10,12 @@ set -e
 cd "$(dirname "$0")"
 OUT=${BLS_OUT:-libblscurve_mi355x.so}
 # up to date = the library was built from exactly these sources (content hash, not time stamps: a copy of the tree need not keep them)
-STAMP=$(cat csrc/* ../include/*.h tools/align_isa.py build.sh | sha256sum | cut -d" " -f1)-$BLS_EXTRA_FLAGS
+STAMP=$(cat csrc/* ../include/*.h tools/align_isa.py build.sh | sha256sum | cut -d" " -f1)-$BLS_EXTRA_FLAGS-$BLS_NO_ALIGN
 if [ "$1" != "-f" ] && [ -f $OUT ] && [ "$(cat $OUT.stamp 2>/dev/null)" = "$STAMP" ]; then
   exit 0
 fi
 LLVM=/opt/rocm/lib/llvm/bin
-# --gpu-max-threads-per-block=64: every kernel is one wave per workgroup; this also gives the out-of-line device
+# --gpu-max-threads-per-block=64: the default launch bound (most kernels are one wave per workgroup; the Fp12 engine kernels and the LDS sort declare their own); this also gives the out-of-line device
 # functions the full 512-register (VGPR+AGPR) budget instead of the 128-VGPR default, so they stop spilling to scratch
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64 $BLS_EXTRA_FLAGS"      # BLS_EXTRA_FLAGS: -D switches of A/B experiments (tools/abn.sh)
 B=build

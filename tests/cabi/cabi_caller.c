@@ -4,6 +4,10 @@
  *   batchVerify(cache) / batchVerifySerial / cache-less batchVerify on the golden n17 batch      -> verdicts (expect 1)
  *   the same on the golden forged_among_many batch                                                -> verdicts (expect 0)
  *   blst_p1s_mult_pippenger-shaped MSM (n = 32): [ptr, NULL] lists and one-pointer-per-element lists -> blst_p1 hex
+ *   the same batches through a context sized for 5 sets (sliced inside the library) and through two contexts (multi-device driver)
+ *   the MSM point-sharded over three contexts, and as partials + mi355_bls_p1s_add
+ *   ContextCoreAggregateVerify-style streaming: init / update x n / finish with a wrong signature -> 0 (the batches carry one
+ *   signature per tuple, not an aggregate), update with the infinity key -> 0
  * The pytest wrapper (tests/test_gpu_cabi.py) compares the verdicts and canonicalises the points against the fixtures. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +52,25 @@ int main(int argc, char** argv) {
         printf("batch%d parallel %d\n", k, mi355_bls_batch_verify(ctx, sets, n, rnd));
         printf("batch%d serial %d\n", k, mi355_bls_batch_verify_serial(ctx, sets, n, rnd));
         printf("batch%d once %d\n", k, mi355_bls_batch_verify_once(sets, n, rnd, 4));
+        /* a cache smaller than the batch: the reference accepts any input.len (bls_batch_verifier.nim:141) */
+        mi355_bls_ctx* tiny = NULL;
+        if (mi355_bls_ctx_create(&tiny, 0, 5)) { fprintf(stderr, "ctx_create(5): %s\n", mi355_bls_last_error()); return 1; }
+        mi355_bls_ctx_set_num_threads(tiny, 4);
+        printf("batch%d sliced %d\n", k, mi355_bls_batch_verify(tiny, sets, n, rnd));
+        printf("batch%d sliced_serial %d\n", k, mi355_bls_batch_verify_serial(tiny, sets, n, rnd));
+        mi355_bls_ctx* pair[2] = {ctx, tiny};
+        printf("batch%d multi %d\n", k, mi355_bls_batch_verify_multi(pair, 2, sets, n, rnd));
+        /* streaming aggregateVerify over the batch's (pk, msg) pairs with tuple 0's signature: not the aggregate -> 0 */
+        mi355_bls_aggv_init(tiny);
+        int upd = 1;
+        for (unsigned i = 0; i < n; i++) upd &= mi355_bls_aggv_update(tiny, sets + 320 * (size_t)i, sets + 320 * (size_t)i + 96, 32);
+        printf("batch%d aggv_updates %d\n", k, upd);
+        printf("batch%d aggv_finish %d\n", k, mi355_bls_aggv_finish(tiny, sets + 128));
+        unsigned char zero_pk[96] = {0};
+        mi355_bls_aggv_init(tiny);
+        printf("batch%d aggv_inf_update %d\n", k, mi355_bls_aggv_update(tiny, zero_pk, sets + 96, 32));
+        printf("batch%d aggv_inf_finish %d\n", k, mi355_bls_aggv_finish(tiny, sets + 128));
+        mi355_bls_ctx_destroy(tiny);
     }
     printf("empty %d\n", mi355_bls_batch_verify(ctx, f, 0, f + 8));
     unsigned np = rd32(p), nbits = rd32(p + 4);
@@ -66,6 +89,23 @@ int main(int argc, char** argv) {
     hex("msm_pointer_list", ret, 144);
     if (mi355_bls_p1s_mult_pippenger(ctx, ret, pl, np, sl, nbits)) { fprintf(stderr, "msm(ctx): %s\n", mi355_bls_last_error()); return 1; }
     hex("msm_ctx", ret, 144);
+    /* point-sharded over three contexts (devices in a real deployment), and the one-process-per-GPU merge of partials */
+    mi355_bls_ctx* three[3] = {ctx, NULL, NULL};
+    if (mi355_bls_ctx_create(&three[1], 0, 8) || mi355_bls_ctx_create(&three[2], 0, 8)) { fprintf(stderr, "ctx_create: %s\n", mi355_bls_last_error()); return 1; }
+    if (mi355_bls_p1s_mult_pippenger_multi(three, 3, ret, pl, np, sl, nbits)) { fprintf(stderr, "msm multi: %s\n", mi355_bls_last_error()); return 1; }
+    hex("msm_multi", ret, 144);
+    unsigned char parts[3 * 144];
+    for (unsigned g = 0; g < 3; g++) {
+        size_t first, count;
+        mi355_bls_msm_shard_range(np, 3, g, &first, &count);
+        const void* gpl[2] = {pts + 96 * first, NULL};
+        const unsigned char* gsl[2] = {sc + 32 * first, NULL};
+        if (mi355_bls_p1s_mult_pippenger(three[g], parts + 144 * g, gpl, count, gsl, nbits)) { fprintf(stderr, "msm part: %s\n", mi355_bls_last_error()); return 1; }
+    }
+    if (mi355_bls_p1s_add(ctx, ret, parts, 3)) { fprintf(stderr, "p1s_add: %s\n", mi355_bls_last_error()); return 1; }
+    hex("msm_partials_added", ret, 144);
+    mi355_bls_ctx_destroy(three[1]);
+    mi355_bls_ctx_destroy(three[2]);
     free(scratch); free(pe); free(se);
     mi355_bls_ctx_destroy(ctx);
     mi355_bls_default_ctx_release();

@@ -31,6 +31,12 @@ def test_plain_c_caller(tmp_path):
     assert (kv["batch0 parallel"], kv["batch0 serial"], kv["batch0 once"]) == ("1", "1", "1")
     assert (kv["batch1 parallel"], kv["batch1 serial"], kv["batch1 once"]) == ("0", "0", "0")
     assert kv["empty"] == "0"
+    # a 5-set context (slices), two contexts (multi-device driver): the same verdicts
+    assert (kv["batch0 sliced"], kv["batch0 sliced_serial"], kv["batch0 multi"]) == ("1", "1", "1")
+    assert (kv["batch1 sliced"], kv["batch1 sliced_serial"], kv["batch1 multi"]) == ("0", "0", "0")
+    # streaming aggregateVerify: every update accepted, a non-aggregate signature rejected; infinity key -> update and finish false
+    for k in ("batch0", "batch1"):
+        assert (kv[k + " aggv_updates"], kv[k + " aggv_finish"], kv[k + " aggv_inf_update"], kv[k + " aggv_inf_finish"]) == ("1", "0", "0", "0")
     want = [v for v in golden("msm")["msm"] if v["n"] == 32][0]["result_affine"]
-    for k in ("msm_contiguous", "msm_pointer_list", "msm_ctx"):
+    for k in ("msm_contiguous", "msm_pointer_list", "msm_ctx", "msm_multi", "msm_partials_added"):
         assert o.g1_to_blst_affine(g1_jac_to_affine(bytes.fromhex(kv[k]))).hex() == want, k
