@@ -168,6 +168,11 @@ int mi355_bls_g1_aggregate_device(mi355_bls_ctx* ctx, const void* d_pks, size_t 
 int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, size_t n, const uint8_t* msg, size_t msg_len, const void* sig);
 int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* ctx, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
                                            const void* sig, void* stream);
+/* The same with the keys sharded over the GPUs of one node: ctxs[g] on device g sums the contiguous block of
+ * keys mi355_bls_msm_shard_range(n, ngpu, g) gives it (aggregateAll, core :179-195), the 144-byte partial sums are added on ctxs[0]
+ * (blst_p1_add_or_double), which runs the one pairing check.  pks: n x 96 B in host memory. */
+int mi355_bls_fast_aggregate_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* pks, size_t n, const uint8_t* msg,
+                                          size_t msg_len, const void* sig);
 
 /* blst_p1s_mult_pippenger (blst_abi.nim:336-340; blst+nim.h:70-72; call sites benchmarks/bls12381_msm_g1.nim:50-59,
  * blst_min_pubkey_sig_core.nim:629): ret = sum_i [k_i mod 2^nbits] P_i as blst_p1 (Jacobian, 144 B).

@@ -84,6 +84,7 @@ def lib():
         L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p, vp]
+        L.mi355_bls_fast_aggregate_verify_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.argtypes = [sz]
         L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.restype = sz
         L.mi355_bls_p1s_mult_pippenger.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
@@ -350,6 +351,18 @@ def fastAggregateVerify(cache, publicKeys, message, signature):
     if n == 0:
         return False
     return bool(_check(lib().mi355_bls_fast_aggregate_verify(cache._h, buf, n, bytes(message), len(message), bytes(signature))))
+
+
+def fastAggregateVerifyMulti(caches, publicKeys, message, signature):
+    """fastAggregateVerify with the keys sharded over several devices (caches[g] on device g), one pairing on caches[0]."""
+    buf = bytes(publicKeys) if isinstance(publicKeys, (bytes, bytearray, memoryview)) else b"".join(publicKeys)
+    if len(buf) % 96 or len(signature) != 192:
+        raise ValueError("public keys are 96-byte, the signature a 192-byte BLST affine image")
+    n = len(buf) // 96
+    if n == 0:
+        return False
+    arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
+    return bool(_check(lib().mi355_bls_fast_aggregate_verify_multi(arr, len(caches), buf, n, bytes(message), len(message), bytes(signature))))
 
 
 def p1s_mult_pippenger(cache, points, scalars, nbits=255):

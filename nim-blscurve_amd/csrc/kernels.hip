@@ -2484,22 +2484,21 @@ extern "C" int mi355_bls_g1_aggregate(mi355_bls_ctx* c, const void* pks, size_t 
     return mi355_bls_g1_aggregate_device(c, c->d_sets, n, nullptr, out_p1);
 }
 
-extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
-                                                      const void* sig, void* stream) {
-    if (!c || !sig || (!msg && msg_len) || msg_len > 4096 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
-    if (n == 0) return 0;                                     // bls_sig_min_pubkey.nim:251-253
-    if (!d_pks) return MI355_BLS_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
+// coreVerifyNoGroupCheck with the aggregate key (core :269-297).  d_pks != nullptr: the n keys are summed first (aggregateAll,
+// beside the hash of the message in latency mode); d_pks == nullptr: the aggregate is already in d_agg1 (the multi-device form).
+static int fav_run(mi355_bls_ctx* c, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len, const void* sig, hipStream_t st) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
     HIPCHK(hipMemcpyAsync(c->d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     // the key sum and the hash of the message are independent: side by side in latency mode
-    hipStream_t sd = (c->coop && c->side) ? c->side : st;
+    hipStream_t sd = (d_pks && c->coop && c->side) ? c->side : st;
     if (sd != st) HIPCHK(hipStreamWaitEvent(sd, c->ev[0], 0));
-    int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, sd);
-    if (rc) return rc;
+    if (d_pks) {
+        int rc = g1_sum_enqueue(c, (const uint8_t*)d_pks, n, sd);
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(c->ev[1], sd));
     k_hash_one<<<1, WAVE, 0, st>>>(c->d_msg, (uint32_t)msg_len, c->dst, c->d_H, c->stride, 0);
     if (sd != st) HIPCHK(hipStreamWaitEvent(st, c->ev[1], 0));
@@ -2516,10 +2515,66 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     c->have_gt = true;
+    c->gt_is_fv = false;
     c->last_n = 0;
-    rc = collect_timings(c, 5);      // [0] g1 sum, [1] hash+setup, [2] lines, [3] products, [4] tail
+    int rc = collect_timings(c, 5);      // [0] g1 sum, [1] hash+setup, [2] lines, [3] products, [4] tail
     if (rc) return rc;
     return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
+}
+extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const void* d_pks, size_t n, const uint8_t* msg, size_t msg_len,
+                                                      const void* sig, void* stream) {
+    if (!c || !sig || (!msg && msg_len) || msg_len > 4096 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;                                     // bls_sig_min_pubkey.nim:251-253
+    if (!d_pks) return MI355_BLS_ERR_ARG;
+    return fav_run(c, d_pks, n, msg, msg_len, sig, (hipStream_t)stream);
+}
+
+// fastAggregateVerify with the keys sharded over several devices: device g sums keys [first_g, first_g +
+// count_g) (mi355_bls_msm_shard_range), the 144-byte partial sums return through pinned host memory, ctxs[0] adds them and runs the
+// one pairing check.  At 3 MB of keys one device is the sensible default; this is the same call for key sets that are not.
+extern "C" int mi355_bls_fast_aggregate_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* pks, size_t n, const uint8_t* msg,
+                                                     size_t msg_len, const void* sig) {
+    if (!ctxs || ngpu == 0 || ngpu > 64 || !sig || (!msg && msg_len) || msg_len > 4096 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
+    if (n == 0) return 0;
+    if (!pks) return MI355_BLS_ERR_ARG;
+    for (size_t g = 0; g < ngpu; g++)
+        if (!ctxs[g]) return MI355_BLS_ERR_ARG;
+    const uint8_t* p = (const uint8_t*)pks;
+    bool live[64] = {};
+    int rc = 0;
+    for (size_t g = 0; g < ngpu && !rc; g++) {
+        size_t first, count;
+        mi355_bls_msm_shard_range(n, (uint32_t)ngpu, (uint32_t)g, &first, &count);
+        if (count == 0) continue;
+        mi355_bls_ctx* c = ctxs[g];
+        rc = io_reserve(c, (count * 96 + 319) / 320);
+        if (rc) break;
+        if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(c->d_sets, p + 96 * first, count * 96, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+            g_err = "staging of a key shard failed";
+            rc = MI355_BLS_ERR_HIP;
+            break;
+        }
+        rc = g1_sum_enqueue(c, c->d_sets, count, nullptr);
+        if (rc) break;
+        if (hipMemcpyAsync(c->h_flags + 160, c->d_agg1, 144, hipMemcpyDeviceToHost, nullptr) != hipSuccess) { g_err = "hipMemcpyAsync (key-sum partial)"; rc = MI355_BLS_ERR_HIP; break; }
+        live[g] = true;
+    }
+    std::vector<uint8_t> parts;
+    for (size_t g = 0; g < ngpu; g++) {                  // every device that was handed work is waited for, also after a failure
+        if (!live[g]) continue;
+        (void)hipSetDevice(ctxs[g]->device);
+        if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) { g_err = "hipStreamSynchronize (key shard)"; rc = MI355_BLS_ERR_HIP; }
+        const uint8_t* h = reinterpret_cast<const uint8_t*>(ctxs[g]->h_flags + 160);
+        parts.insert(parts.end(), h, h + 144);
+    }
+    if (rc) return rc;
+    mi355_bls_ctx* c0 = ctxs[0];
+    HIPCHK(hipSetDevice(c0->device));
+    HIPCHK(hipMemcpyAsync(c0->d_export, parts.data(), parts.size(), hipMemcpyHostToDevice, nullptr));
+    k_jac_sum_blst<fp><<<1, WAVE, 0, nullptr>>>(c0->d_export, (uint32_t)(parts.size() / 144), 36, c0->d_agg1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));               // `parts` (pageable) has been consumed
+    return fav_run(c0, nullptr, n, msg, msg_len, sig, nullptr);
 }
 
 extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks, size_t n, const uint8_t* msg, size_t msg_len, const void* sig) {

@@ -67,3 +67,14 @@ def test_fast_aggregate_verify_32768(m, cache):
     assert co.fast_aggregate_verify(pks, msg, sig) is True and co.fast_aggregate_verify(pks, msg, bad) is False
     # dropping one key breaks it
     assert m.fastAggregateVerify(cache, pks[96:], msg, sig) is False
+    # the same keys sharded over 1, 3 and 8 contexts (devices in a deployment): same verdicts, same GT value
+    gt = cache.fetch(4, 576) if m.fastAggregateVerify(cache, pks, msg, sig) else None
+    for ngpu in (1, 3, 8):
+        caches = [m.BatchedBLSVerifierCache.init(max_sets=64) for _ in range(ngpu)]
+        assert m.fastAggregateVerifyMulti(caches, pks, msg, sig) is True
+        assert caches[0].fetch(4, 576) == gt
+        assert m.fastAggregateVerifyMulti(caches, pks, msg, bad) is False
+        assert m.fastAggregateVerifyMulti(caches, pks[96:], msg, sig) is False
+        assert m.fastAggregateVerifyMulti(caches, pks[:96 * 2], msg, sig) is False          # 2 keys on 8 devices: empty shards
+        for c in caches:
+            c.close()
