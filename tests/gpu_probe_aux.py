@@ -22,6 +22,19 @@ if "msm" in what:
     for _ in range(6):
         m.p1s_mult_pippenger_device(cache, dp.data_ptr(), nm, ds.data_ptr(), 255)
     print("msm", cache.timings())
+    # two MSMs in flight (two contexts, two streams, results left in device memory): what a caller that pipelines its calls gets
+    import time
+    c2 = [m.BatchedBLSVerifierCache.init(max_sets=64) for _ in range(2)]
+    s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = [torch.zeros(144, dtype=torch.uint8, device=dev) for _ in range(2)]
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            m.p1s_mult_pippenger_partial_device(c2[i % 2], outs[i % 2].data_ptr(), dp.data_ptr(), nm, ds.data_ptr(), 255, s2[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+    print("msm two in flight: %.3f ms per MSM, %.1f M points/s" % (dt * 1e3, nm / dt / 1e6))
 if "fav" in what:
     n = 32768
     sks = [bench.secret_key((1 << 41) + i) for i in range(n)]

@@ -6,7 +6,7 @@ for r in $(seq $rounds); do for v in "$@"; do
   cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so; touch $R/nim-blscurve_amd/libblscurve_mi355x.so
   echo -n "$v "
   case "${WHAT:-bench}" in
-    msm) timeout 300 python3 $R/tests/gpu_probe_aux.py msm 2>/dev/null | tail -1 ;;
+    msm) timeout 300 python3 $R/tests/gpu_probe_aux.py msm 2>/dev/null | tail -2 | tr '\n' ' '; echo ;;
     lat) timeout 300 python3 $R/tests/gpu_probe_lat.py 2>/dev/null | grep -E "FAV n=32768|batch n=(64|4096|65536):" | cut -c1-60 | tr '\n' ';'; echo ;;
     *) timeout 300 python3 $R/bench.py --steps 30 --warmup 4 --no-cpu --no-aux 2>/dev/null | head -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), round(d['ms_one_caller'],2), {k:round(v,3) for k,v in d['kernel_ms_alone'].items()}, {k:round(v,3) for k,v in d.get('tail_ms_alone',{}).items()})" ;;
