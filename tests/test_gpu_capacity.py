@@ -171,3 +171,31 @@ def test_staging_grows_for_the_entry_points_around_the_path(m):
     assert m.fastAggregateVerify(tiny, pks[:-1], msg, agg) is False
     for c in (small, small2, big, tiny):
         c.close()
+
+
+def test_sliced_batches_in_flight_on_several_contexts(m, batch):
+    """Three callers (context + stream each), each with a sliced batch in flight at the same time, latency- and throughput-mode
+    contexts mixed, batches chained with `after`: every GT value equals the C restatement's, a tampered batch among them is caught."""
+    import torch
+    import c_oracle as co
+    rec, n = batch
+    nt = 333
+    ok, st = co.batch_verify(rec, RND, nt, stages=True)
+    bad = bytearray(rec)
+    bad[320 * 7777 + 128 + 5] ^= 2
+    okb, stb = co.batch_verify(bytes(bad), RND, nt, stages=True)
+    assert ok and not okb
+    d_ok = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    caches = [m.BatchedBLSVerifierCache.init(max_sets=cap, numThreads=nt) for cap in (4096, 3000, 5000)]
+    caches[1].set_cooperative(False)
+    for rnd_round in range(3):
+        plan = [d_ok, d_bad, d_ok] if rnd_round == 1 else [d_ok, d_ok, d_bad] if rnd_round == 2 else [d_ok, d_ok, d_ok]
+        for i, (c, s, d) in enumerate(zip(caches, streams, plan)):
+            c.submit_device(d.data_ptr(), n, RND, s.cuda_stream, after=caches[i - 1] if i else None)
+        for c, d in zip(caches, plan):
+            assert c.wait() is (d is d_ok)
+            assert c.fetch(4, 576) == (st["gt"] if d is d_ok else stb["gt"])
+    for c in caches:
+        c.close()
