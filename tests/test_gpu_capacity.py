@@ -182,7 +182,7 @@ def test_sliced_batches_in_flight_on_several_contexts(m, batch):
     nt = 333
     ok, st = co.batch_verify(rec, RND, nt, stages=True)
     bad = bytearray(rec)
-    bad[320 * 7777 + 128 + 5] ^= 2
+    bad[320 * 7777 + 96] ^= 2                      # another message: every point stays on its curve, so the GT values are comparable
     okb, stb = co.batch_verify(bytes(bad), RND, nt, stages=True)
     assert ok and not okb
     d_ok = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
