@@ -199,3 +199,23 @@ def test_sliced_batches_in_flight_on_several_contexts(m, batch):
             assert c.fetch(4, 576) == (st["gt"] if d is d_ok else stb["gt"])
     for c in caches:
         c.close()
+
+
+@pytest.mark.parametrize("cap,nt", [(700, 2), (333, 1), (64, 4096), (1, 3)])
+def test_chunks_spanning_many_slices(m, cap, nt):
+    """A blinding chain that runs through three or more slices (chunk of 1 500 tuples, slices of 600: the carried chain state is read
+    and written by the same lane), the serial chain, one-tuple slices (cap = 1: every slice is a single tuple) - GT equal to the C
+    restatement's every time."""
+    import c_oracle as co
+    n = 3000 if cap > 1 else 37
+    rec = co.make_batch(n, seed=77000 + cap)
+    ok, st = co.batch_verify(rec, RND, nt if nt > 1 else 0, stages=True)
+    assert ok
+    cache = m.BatchedBLSVerifierCache.init(max_sets=cap, numThreads=nt)
+    assert m.batchVerify(cache, rec, RND) is True                   # numThreads = 1 -> the serial chain (:440)
+    assert cache.fetch(4, 576) == st["gt"]
+    bad = bytearray(rec)
+    bad[320 * (n - 2) + 97] ^= 1
+    okb, stb = co.batch_verify(bytes(bad), RND, nt if nt > 1 else 0, stages=True)
+    assert not okb and m.batchVerify(cache, bytes(bad), RND) is False and cache.fetch(4, 576) == stb["gt"]
+    cache.close()
