@@ -91,6 +91,19 @@ int mi355_bls_batch_submit_device(mi355_bls_ctx* ctx, const void* d_sets, size_t
                                   mi355_bls_ctx* after);
 int mi355_bls_batch_wait(mi355_bls_ctx* ctx);
 
+/* Many independent batches in ONE device pass (no reference counterpart: the reference verifies one batch per call and gets its
+ * concurrency from caller threads; on the device, small batches cannot fill the chip and the number of HIP hardware queues caps
+ * how many calls run side by side).  sets: the tuples of batch 0, then batch 1, ... (counts[b] of them each, 320-byte records),
+ * rnds: k x 32 bytes, one secureRandomBytes per batch; verdicts[b] receives what mi355_bls_batch_verify_once(batch b, rnd b,
+ * num_threads) would return (an empty batch: 0).  Every tuple keeps the blinding scalar it has in its own batch (own chain
+ * partition B = min(n_b, num_threads), serial chain for n_b < 3 or num_threads = 1, bls_batch_verifier.nim:440); the union is
+ * verified at once, and the product of the k batch checks is one iff every batch verifies (up to the 2^-64 of the random linear
+ * combination, the reference's own bound).  If it is not, or if the union exceeds the context's capacity, the batches are
+ * verified one by one.  Returns 1 when every batch verified, 0 otherwise, negative on runtime failure. */
+int mi355_bls_batch_verify_many(mi355_bls_ctx* ctx, const void* sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[]);
+int mi355_bls_batch_verify_many_device(mi355_bls_ctx* ctx, const void* d_sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[],
+                                       void* stream);
+
 /* Multi-GPU sharding (replaces processSingleChunk + merge, bls_batch_verifier.nim:326-369).
  * The global batch of n_total sets is cut into B = min(n_total, num_threads) chunks by
  * parallel_chunks (parallel_chunks.nim:42-66); this call processes chunks [chunk_lo, chunk_hi),

@@ -54,6 +54,8 @@ def lib():
         L.mi355_bls_batch_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp]
         L.mi355_bls_batch_submit_device.argtypes = [vp, vp, sz, ctypes.c_char_p, vp, vp]
         L.mi355_bls_batch_wait.argtypes = [vp]
+        L.mi355_bls_batch_verify_many.argtypes = [vp, vp, ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_char_p]
+        L.mi355_bls_batch_verify_many_device.argtypes = [vp, vp, ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_char_p, vp]
         L.mi355_bls_batch_shard_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, ctypes.c_char_p, ctypes.POINTER(i32)]
         L.mi355_bls_batch_shard_submit_device.argtypes = [vp, vp, sz, u32, u32, ctypes.c_char_p, vp, vp]
         L.mi355_bls_batch_shard_wait.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
@@ -299,6 +301,32 @@ def batchVerifyOnce(input_, secureRandomBytes, numThreads=DEFAULT_NUM_THREADS):
     if n == 0:
         return False
     return bool(_check(lib().mi355_bls_batch_verify_once(rec, n, _rnd32(secureRandomBytes), numThreads)))
+
+
+def batchVerifyMany(cache, inputs, secureRandomBytes_list):
+    """k independent batches in ONE device pass (mi355_bls_batch_verify_many): inputs[b] is batch b (records or SignatureSet list),
+    secureRandomBytes_list[b] its random bytes.  -> [bool] * k, each what batchVerify(cache, inputs[b], rnd[b]) returns."""
+    recs = [_as_records(x) for x in inputs]
+    if len(recs) != len(secureRandomBytes_list):
+        raise ValueError("one secureRandomBytes per batch")
+    k = len(recs)
+    if k == 0:
+        return []
+    counts = (ctypes.c_size_t * k)(*[len(r) // SIGSET_BYTES for r in recs])
+    rnds = b"".join(_rnd32(r) for r in secureRandomBytes_list)
+    out = ctypes.create_string_buffer(k)
+    _check(lib().mi355_bls_batch_verify_many(cache._h, b"".join(recs) or b"\0", counts, rnds, k, out))
+    return [bool(v) for v in out.raw]
+
+
+def batchVerifyMany_device(cache, d_ptr, counts, secureRandomBytes_list, stream=0):
+    """Same with the tuples of all batches contiguous in device memory."""
+    k = len(counts)
+    carr = (ctypes.c_size_t * k)(*counts)
+    rnds = b"".join(_rnd32(r) for r in secureRandomBytes_list)
+    out = ctypes.create_string_buffer(k)
+    _check(lib().mi355_bls_batch_verify_many_device(cache._h, d_ptr, carr, rnds, k, out, stream))
+    return [bool(v) for v in out.raw]
 
 
 def batchVerifySerial(cache, input_, secureRandomBytes):

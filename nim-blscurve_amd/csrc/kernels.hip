@@ -261,6 +261,45 @@ __global__ void __launch_bounds__(WAVE) k_blind(const uint8_t* __restrict__ rnd,
     }
 }
 
+// Many independent batches in one pass (mi355_bls_batch_verify_many): lane t is chain `c` of batch `b` - batch b has meta[b] =
+// {first tuple, tuple count, chains B_b = min(n_b, num_threads), first lane} and its own secureRandomBytes rnds[32 b ..]; the chain
+// is exactly the one k_blind computes for that batch alone.  Batches that take the serial chain have B_b = 0 here (host-computed).
+struct many_meta {
+    uint64_t first, count;
+    uint32_t chains, lane0;
+};
+__global__ void __launch_bounds__(WAVE) k_blind_many(const uint8_t* __restrict__ rnds, const many_meta* __restrict__ meta, uint32_t nbatch, uint32_t nlanes,
+                                                     uint64_t* __restrict__ r_out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlanes) return;
+    uint32_t lo = 0, hi = nbatch;                        // the batch whose lane range holds t: the last b with lane0 <= t
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (meta[mid].lane0 <= t) lo = mid; else hi = mid;
+    }
+    const many_meta mb = meta[lo];
+    uint64_t c = t - mb.lane0, nchunks = mb.chains, base = mb.count / nchunks, rem = mb.count % nchunks;
+    uint64_t off = c < rem ? (base + 1) * c : base * c + rem, len = c < rem ? base + 1 : base;
+    const uint8_t* rnd = rnds + 32 * (size_t)lo;
+    sha256_ctx ctx;
+    sha256_begin(ctx);
+    for (int i = 0; i < 32; i++) sha256_put(ctx, rnd[i]);
+    for (int i = 0; i < 8; i++) sha256_put(ctx, (uint8_t)(c >> (8 * i)));
+    uint32_t seed[8];
+    sha256_end(ctx, seed);
+    for (uint64_t j = 0; j < len; j++) {
+        uint64_t r;
+        do {
+            uint32_t nx[8];
+            sha256_of_digest(seed, nx);
+#pragma unroll
+            for (int i = 0; i < 8; i++) seed[i] = nx[i];
+            r = digest_low_u64_le(seed);
+        } while (r == 0);
+        r_out[mb.first + off + j] = r;
+    }
+}
+
 // Batch form of hash-to-G2 in two kernels.  k_hash_map: TWO lanes per message, lane j maps u_j (SSWU + 3-isogeny:
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
@@ -1910,10 +1949,9 @@ static int enqueue_line_products(mi355_bls_ctx* c, uint32_t npairs, hipStream_t 
 // the signature side (bucket fold).  A batch that fills the chip runs them one after the other on the caller's stream (each is a
 // whole-chip kernel).  A small batch in latency mode runs the last two on the context's side stream beside the hashing: they
 // are all latency-bound there (a few waves each), so this takes about a millisecond off the call.
+static int run_pairs(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, hipStream_t st);
 static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
                      size_t tuple_base, size_t n, int serial, size_t serial_off, uint32_t slice, hipStream_t st) {
-    uint32_t n32 = (uint32_t)n;
-    uint32_t nb = (n32 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[0], st));
     if (serial) {
         HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data() + serial_off, n * 8, hipMemcpyHostToDevice, st));
@@ -1921,6 +1959,13 @@ static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, ui
         k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, n, c->d_carry + 8 * (slice & 1),
                                                                 c->d_carry + 8 * ((slice + 1) & 1), c->d_r);
     }
+    return run_pairs(c, d_sets, n, st);
+}
+// Everything behind the blinding scalars (d_r[0 .. n) are ready on `st`): hashing, [r]PK, the signature side, Miller lines, line
+// products, the committed state of these n tuples in d_states slot 0.
+static int run_pairs(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, hipStream_t st) {
+    uint32_t n32 = (uint32_t)n;
+    uint32_t nb = (n32 + WAVE - 1) / WAVE;
     HIPCHK(hipEventRecord(c->ev[1], st));
     const bool fork = c->coop && c->side && n32 <= 16 * c->slots;       // pk + signature side beside the hashing
     // A whole-chip batch of ONE caller (latency mode): the signature side and the Miller lines of its extra pairs run on the side
@@ -2136,6 +2181,118 @@ static int verify_host(mi355_bls_ctx* c, const void* sets, size_t n, const uint8
 
 extern "C" int mi355_bls_batch_verify(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 0); }
 extern "C" int mi355_bls_batch_verify_serial(mi355_bls_ctx* c, const void* sets, size_t n, const uint8_t rnd[32]) { return verify_host(c, sets, n, rnd, 1); }
+
+// ------------------------------------------------------------------------------------------
+// Many independent batches in ONE device pass.  A host that verifies many SMALL batches (a few thousand sets each: one per block or
+// gossip aggregate) cannot fill the chip with one of them, and the number of HIP hardware queues caps how many calls run side by
+// side ("Other rows").  Here the k batches are verified as the union of their tuples with every tuple keeping
+// the blinding scalar it has in its OWN batch (its own secureRandomBytes, its own chain partition, batchVerify's dispatch rule per
+// batch): the merged product is the product of the k batch products, so it is one iff every batch verifies - up to the 2^-64 of
+// the random linear combination, which is the reference's own soundness bound for ONE batch.  If the merged check passes, every
+// verdict is true (the common case, at whole-chip throughput); if it fails, the batches are verified one by one to find the
+// culprits - the optimistic scheme clients already wrap around batchVerify.  Verdicts are exactly those of k separate calls.
+// ------------------------------------------------------------------------------------------
+static int verify_many(mi355_bls_ctx* c, const uint8_t* d_src, const uint8_t* h_src, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[],
+                       hipStream_t st) {
+    if (!c || !counts || !rnds || !verdicts || (!d_src && !h_src)) return MI355_BLS_ERR_ARG;
+    if (c->pending) {
+        g_err = "a batch submitted on this context has not been waited for";
+        return MI355_BLS_ERR_ARG;
+    }
+    size_t total = 0;
+    for (size_t b = 0; b < k; b++) {
+        verdicts[b] = 0;
+        total += counts[b];
+    }
+    if (total == 0) return 0;                                     // every batch empty: every verdict false (bls_batch_verifier.nim:137-139)
+    HIPCHK(hipSetDevice(c->device));
+    bool merged_ok = false;
+    if (total <= c->cap && k <= 65536) {
+        // ---- merged pass
+        std::vector<many_meta> meta;
+        std::vector<uint8_t> rr;
+        uint32_t lanes = 0;
+        size_t first = 0;
+        c->h_r.assign(total, 0);
+        bool any_serial = false;
+        for (size_t b = 0; b < k; b++) {
+            size_t nb_ = counts[b];
+            if (nb_ == 0) continue;                               // an empty batch is false by itself and takes no part
+            const bool parallel = c->num_threads > 1 && nb_ >= 3; // batchVerify's dispatch (bls_batch_verifier.nim:440)
+            if (parallel) {
+                uint32_t B = (uint32_t)(nb_ < c->num_threads ? nb_ : c->num_threads);
+                meta.push_back(many_meta{first, nb_, B, lanes});
+                rr.insert(rr.end(), rnds + 32 * b, rnds + 32 * b + 32);
+                lanes += B;
+            } else {
+                host_serial_chain(rnds + 32 * b, nb_, c->h_r.data() + first);
+                any_serial = true;
+            }
+            first += nb_;
+        }
+        {   // meta and the per-batch random bytes ride in the wire-format staging buffer (unused on this path)
+            int rcr = io_reserve(c, (meta.size() * (sizeof(many_meta) + 32) + 64 + 319) / 320 + 1);
+            if (rcr) return rcr;
+        }
+        const uint8_t* d_sets = d_src;
+        if (!d_sets) {
+            HIPCHK(hipMemcpyAsync(c->d_sets, h_src, total * 320, hipMemcpyHostToDevice, st));
+            d_sets = c->d_sets;
+        }
+        HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
+        HIPCHK(hipEventRecord(c->ev[0], st));
+        if (any_serial) HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data(), total * 8, hipMemcpyHostToDevice, st));      // serial batches' scalars (zeros elsewhere, overwritten below)
+        if (lanes) {
+            many_meta* d_meta = reinterpret_cast<many_meta*>(c->d_comp);
+            uint8_t* d_rr = c->d_comp + ((meta.size() * sizeof(many_meta) + 63) / 64) * 64;
+            HIPCHK(hipMemcpyAsync(d_meta, meta.data(), meta.size() * sizeof(many_meta), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_rr, rr.data(), rr.size(), hipMemcpyHostToDevice, st));
+            k_blind_many<<<(lanes + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_rr, d_meta, (uint32_t)meta.size(), lanes, c->d_r);
+        }
+        int rc = run_pairs(c, d_sets, total, st);
+        if (rc) return rc;
+        k_tail<<<1, tail_threads(c), 0, st>>>(c->d_L, c->d_states, 1, 2, c->d_gt, c->d_flags + 1, 144, 0);
+        HIPCHK(hipEventRecord(c->ev[8], st));
+        uint32_t fl[2];
+        HIPCHK(hipMemcpyAsync(fl, c->d_flags, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));                         // also: meta / rr / h_r (host vectors) have been consumed
+        c->have_gt = true;
+        c->gt_is_fv = false;
+        (void)collect_timings(c, 7);
+        merged_ok = fl[0] == 0 && fl[1] == 1;
+    }
+    if (merged_ok) {
+        int all = 1;
+        for (size_t b = 0; b < k; b++) {
+            verdicts[b] = counts[b] ? 1 : 0;
+            all &= verdicts[b];
+        }
+        return all;
+    }
+    // ---- some batch fails (or the union exceeds the workspace): one by one, exactly as k separate batchVerify calls
+    int all = 1;
+    size_t first = 0;
+    for (size_t b = 0; b < k; b++) {
+        size_t nb_ = counts[b];
+        int v = 0;
+        if (nb_) {
+            const int serial = (c->num_threads > 1 && nb_ >= 3) ? 0 : 1;
+            v = verify_common(c, d_src ? d_src + 320 * first : nullptr, d_src ? nullptr : h_src + 320 * first, nb_, rnds + 32 * b, serial, st);
+            if (v < 0) return v;
+        }
+        verdicts[b] = (uint8_t)v;
+        all &= v;
+        first += nb_;
+    }
+    return all;
+}
+extern "C" int mi355_bls_batch_verify_many(mi355_bls_ctx* c, const void* sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[]) {
+    return verify_many(c, nullptr, (const uint8_t*)sets, counts, rnds, k, verdicts, nullptr);
+}
+extern "C" int mi355_bls_batch_verify_many_device(mi355_bls_ctx* c, const void* d_sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[],
+                                                  void* stream) {
+    return verify_many(c, (const uint8_t*)d_sets, nullptr, counts, rnds, k, verdicts, (hipStream_t)stream);
+}
 
 static int shard_enqueue(mi355_bls_ctx* c, const void* d_sets, const uint8_t* h_sets, size_t n_total, uint32_t chunk_lo, uint32_t chunk_hi, const uint8_t rnd[32],
                          hipStream_t st, mi355_bls_ctx* after) {

@@ -73,6 +73,23 @@ int main(int argc, char** argv) {
         mi355_bls_ctx_destroy(tiny);
     }
     printf("empty %d\n", mi355_bls_batch_verify(ctx, f, 0, f + 8));
+    {   /* both batches (and an empty one between them) in ONE device pass: per-batch verdicts */
+        const unsigned char* q = f + 8;
+        unsigned n0 = rd32(q), n1 = rd32(q + 4 + 320 * (size_t)n0 + 32);
+        const unsigned char* s0 = q + 4;
+        const unsigned char* s1 = s0 + 320 * (size_t)n0 + 32 + 4;
+        unsigned char* all = (unsigned char*)malloc(320 * (size_t)(n0 + n1));
+        memcpy(all, s0, 320 * (size_t)n0);
+        memcpy(all + 320 * (size_t)n0, s1, 320 * (size_t)n1);
+        unsigned char rnds[96], verdicts[3] = {9, 9, 9};
+        memcpy(rnds, s0 + 320 * (size_t)n0, 32);
+        memset(rnds + 32, 7, 32);
+        memcpy(rnds + 64, s1 + 320 * (size_t)n1, 32);
+        size_t counts[3] = {n0, 0, n1};
+        int rcm = mi355_bls_batch_verify_many(ctx, all, counts, rnds, 3, verdicts);
+        printf("many %d%d%d%d\n", rcm, verdicts[0], verdicts[1], verdicts[2]);
+        free(all);
+    }
     unsigned np = rd32(p), nbits = rd32(p + 4);
     const unsigned char* pts = p + 8;
     const unsigned char* sc = pts + 96 * (size_t)np;

@@ -31,6 +31,7 @@ def test_plain_c_caller(tmp_path):
     assert (kv["batch0 parallel"], kv["batch0 serial"], kv["batch0 once"]) == ("1", "1", "1")
     assert (kv["batch1 parallel"], kv["batch1 serial"], kv["batch1 once"]) == ("0", "0", "0")
     assert kv["empty"] == "0"
+    assert kv["many"] == "0100"              # rc 0 (not all verified); golden n17 true, the empty batch false, forged_among_many false
     # a 5-set context (slices), two contexts (multi-device driver): the same verdicts
     assert (kv["batch0 sliced"], kv["batch0 sliced_serial"], kv["batch0 multi"]) == ("1", "1", "1")
     assert (kv["batch1 sliced"], kv["batch1 sliced_serial"], kv["batch1 multi"]) == ("0", "0", "0")
