@@ -1619,7 +1619,6 @@ struct mi355_bls_ctx {
     size_t mstride = 0;
     uint4* d_P = nullptr;
     uint4* d_lines = nullptr;
-    uint32_t* d_spart = nullptr;
     // bucket fold of the signatures (batches of >= SIG_BUCKET_MIN tuples)
     uint32_t* d_sig_pts = nullptr;   // signatures in the device representation, cap x 4 x FPW words
     uint32_t* d_sig_sorted = nullptr;// counting sort by digit: nwin x cap tuple indices
@@ -1683,7 +1682,7 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_spart, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_gt_fv, c->d_carry, c->d_blob, c->d_flags, c->d_export};
+    void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_gt_fv, c->d_carry, c->d_blob, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -1738,7 +1737,6 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_M, c->mstride * 6 * 64);
     ALLOC(c->d_P, c->stride * 3 * 64);
     ALLOC(c->d_lines, c->stride * 6 * 64 * (size_t)N_LINES);
-    ALLOC(c->d_spart, 1024);
     ALLOC(c->d_sig_pts, max_sets * 4 * FPW * 4);
     ALLOC(c->d_sig_sorted, max_sets * 16 * 4);
     ALLOC(c->d_sig_hist, 3 * SIG_SLOTS_MAX * 4);
