@@ -186,6 +186,10 @@ int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* ctx, const void* d_pks
  * (blst_p1_add_or_double), which runs the one pairing check.  pks: n x 96 B in host memory. */
 int mi355_bls_fast_aggregate_verify_multi(mi355_bls_ctx* const ctxs[], size_t ngpu, const void* pks, size_t n, const uint8_t* msg,
                                           size_t msg_len, const void* sig);
+/* coreVerifyNoGroupCheck on an AggregatePublicKey the caller already holds (core :269-297): agg_p1 = blst_p1 (Jacobian, 144 B), e.g.
+ * mi355_bls_p1s_add of the per-rank mi355_bls_g1_aggregate_device partial sums of a key-sharded fastAggregateVerify (one process per
+ * GPU).  Aggregate at infinity -> 0. */
+int mi355_bls_verify_aggregate(mi355_bls_ctx* ctx, const uint8_t agg_p1[144], const uint8_t* msg, size_t msg_len, const void* sig);
 
 /* blst_p1s_mult_pippenger (blst_abi.nim:336-340; blst+nim.h:70-72; call sites benchmarks/bls12381_msm_g1.nim:50-59,
  * blst_min_pubkey_sig_core.nim:629): ret = sum_i [k_i mod 2^nbits] P_i as blst_p1 (Jacobian, 144 B).

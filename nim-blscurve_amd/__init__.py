@@ -87,6 +87,7 @@ def lib():
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p, vp]
         L.mi355_bls_fast_aggregate_verify_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
+        L.mi355_bls_verify_aggregate.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.argtypes = [sz]
         L.mi355_bls_p1s_mult_pippenger_scratch_sizeof.restype = sz
         L.mi355_bls_p1s_mult_pippenger.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
@@ -391,6 +392,13 @@ def fastAggregateVerifyMulti(caches, publicKeys, message, signature):
         return False
     arr = (ctypes.c_void_p * len(caches))(*[c._h for c in caches])
     return bool(_check(lib().mi355_bls_fast_aggregate_verify_multi(arr, len(caches), buf, n, bytes(message), len(message), bytes(signature))))
+
+
+def verifyAggregate(cache, aggregate_p1, message, signature):
+    """coreVerifyNoGroupCheck (core :269-297) on a 144-byte blst_p1 aggregate public key the caller holds."""
+    if len(aggregate_p1) != 144 or len(signature) != 192:
+        raise ValueError("aggregate: 144-byte blst_p1, signature: 192-byte blst_p2_affine")
+    return bool(_check(lib().mi355_bls_verify_aggregate(cache._h, bytes(aggregate_p1), bytes(message), len(message), bytes(signature))))
 
 
 def p1s_mult_pippenger(cache, points, scalars, nbits=255):

@@ -2684,6 +2684,16 @@ extern "C" int mi355_bls_fast_aggregate_verify_device(mi355_bls_ctx* c, const vo
     return fav_run(c, d_pks, n, msg, msg_len, sig, (hipStream_t)stream);
 }
 
+// coreVerifyNoGroupCheck on an aggregate the caller already holds (blst_min_pubkey_sig_core.nim:269-297 with an AggregatePublicKey:
+// the `finish`-less form): agg_p1 = blst_p1 (Jacobian, 144 B), e.g. the sum of the per-rank partial key sums of a key-sharded
+// fastAggregateVerify (mi355_bls_g1_aggregate_device per rank, mi355_bls_p1s_add on rank 0).  Aggregate at infinity -> 0.
+extern "C" int mi355_bls_verify_aggregate(mi355_bls_ctx* c, const uint8_t agg_p1[144], const uint8_t* msg, size_t msg_len, const void* sig) {
+    if (!c || !agg_p1 || !sig || (!msg && msg_len) || msg_len > 4096) return MI355_BLS_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_agg1, agg_p1, 144, hipMemcpyHostToDevice));
+    return fav_run(c, nullptr, 1, msg, msg_len, sig, nullptr);
+}
+
 // fastAggregateVerify with the keys sharded over several devices: device g sums keys [first_g, first_g +
 // count_g) (mi355_bls_msm_shard_range), the 144-byte partial sums return through pinned host memory, ctxs[0] adds them and runs the
 // one pairing check.  At 3 MB of keys one device is the sensible default; this is the same call for key sets that are not.

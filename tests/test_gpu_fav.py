@@ -78,3 +78,9 @@ def test_fast_aggregate_verify_32768(m, cache):
         assert m.fastAggregateVerifyMulti(caches, pks[:96 * 2], msg, sig) is False          # 2 keys on 8 devices: empty shards
         for c in caches:
             c.close()
+    # one process per GPU: per-rank partial key sums (aggregateAll), added, then the pairing check on the aggregate
+    parts = [m.aggregateAll(cache, pks[96 * a:96 * b]) for a, b in ((0, 10000), (10000, 20001), (20001, n))]
+    agg = m.p1s_add(cache, parts)
+    assert m.verifyAggregate(cache, agg, msg, sig) is True and cache.fetch(4, 576) == gt
+    assert m.verifyAggregate(cache, agg, msg, bad) is False
+    assert m.verifyAggregate(cache, bytes(144), msg, sig) is False                        # aggregate at infinity
