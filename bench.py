@@ -5,8 +5,10 @@ A step = one batchVerify of a 65 536-tuple batch per GPU (the size BASELINE.json
 resident in HBM before the timed region; `--inflight` (default 3) independent caller contexts keep that many
 batches in flight so the serial tail of one overlaps the wide kernels of another.  N > 1: one process per GPU, each
 verifies its own 65 536-tuple shard of one global batch (weak scaling); the only exchange is an RCCL all_gather of
-the 640-byte shard blob (576-byte committed Fp12 state + ok word) per rank on DEVICE buffers, enqueued behind the
-shard's kernels, then one final exponentiation on rank 0 - no host round trip inside a step.
+the 640-byte shard blob (576-byte committed Fp12 state + ok word) per rank on DEVICE buffers, then one final exponentiation on
+rank 0.  The blob itself never crosses PCIe; the host does wait for the shard (`shard_wait`: a host-side stream wait and a
+580-byte D2H of the ok word) BEFORE it issues the collective, because torch enqueues collectives on a stream of its own and one
+that waits there for a whole batch blocks the hardware queue it shares with a caller stream.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   value_one_caller / value_host_buffers   one blocking caller, HBM-resident and PCIe-inclusive (outside the timed region)
@@ -45,7 +47,7 @@ KERNEL_BYTES = {"k_hash_map": 32 + 2 * 288, "k_hash_clear": 2 * 288 + 288, "k_pk
 # 32x32+64-bit multiply-adds (v_mad_i64_i32 / v_mad_u64_u32) per tuple and kernel of the one-lane-per-tuple pipeline:
 # a census of the real formulas (tests/host_emu: emu_mad_census; tests/test_host_emu.py pins this table to it)
 MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 263081, "k_sig_bucket": 87808, "k_lines": 759997,
-                 "k_lineprod": 1039584}
+                 "k_lineprod": 1119552}
 MAD_ISSUE_CYCLES = 4.0          # one wave64 VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md, issue cost table)
 CLOCK_HZ = 2.4e9                # peak engine clock; under this load the chip sustains less (DVFS), see DESIGN.md section 4
 MAD_PEAK_MEASURED = 256 * 4 * 64 / 2.28e-9      # multiply-adds/s the chip issues in the micro-benchmark (profiles/r01_ubench_valu.txt)
@@ -479,8 +481,8 @@ def main():
             "stage_ms_one_caller": one.get("stage_ms_one_caller"),
             "value_host_buffers": one.get("value_host_buffers"),
             "ms_host_buffers": one.get("ms_host_buffers"),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
+            "roofline": {"bound": "hbm", "bound_actual": "int_mad", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
                          "kernel_ms_timed_region": dom_ms, "kernel_ms_alone": alone[dom],
                          "achieved_kernel_alone": alg_bytes / (alone[dom] * 1e-3) / 1e9,
                          "frac_kernel_alone": alg_bytes / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -584,16 +586,19 @@ def one_caller_rows(m, cache, cache_tp, stream, d_sets, n, n_total, lo, hi, rnd,
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r02_pmc_summary.json, else r01: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is committed for that kernel."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    """(HBM bytes per launch of the dominant kernel, file it was read from): the NEWEST committed rocprofv3 --pmc summary
+    (profiles/rNN_pmc_summary.json, highest NN: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  (None, None) when no profile is committed for that kernel."""
+    import glob
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")) if re.search(r"r(\d+)_pmc_summary\.json$", f)]
+    for f in sorted(files, key=lambda f: int(re.search(r"r(\d+)_pmc_summary\.json$", f).group(1)), reverse=True):
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return d[kernel]["hbm_bytes_corrected"]
+            d = json.load(open(f))
+            return d[kernel]["hbm_bytes_corrected"], "profiles/" + os.path.basename(f)
         except Exception:
             continue
-    return None
+    return None, None
 
 
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001

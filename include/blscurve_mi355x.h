@@ -50,6 +50,15 @@ int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets);
 void mi355_bls_ctx_destroy(mi355_bls_ctx* ctx);
 const char* mi355_bls_last_error(void);
 
+/* HIP hardware queues.  HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
+ * queue run strictly in turn.  Whole-chip batches do not care; a host that keeps MANY SMALL batches in flight (one context + stream
+ * each; 4 096-tuple batches: 1.4 M verifications/s with 4 queues, 2.3 M/s with 8; more than 8 abort in the runtime) should run with
+ * GPU_MAX_HW_QUEUES=8.  The variable is read when the HIP runtime initialises, so it is the HOST's to set - in its environment, or by
+ * calling this helper ONCE from its main thread before anything in the process touches HIP (setenv is not thread-safe, and the
+ * setting changes queue behaviour for every HIP user of the process: torch, RCCL).  The library never edits the environment on its
+ * own.  Returns 1 if GPU_MAX_HW_QUEUES is now set (an existing value is kept), 0 if MI355_BLS_NO_ENV=1 forbids it or setenv failed. */
+int mi355_bls_recommend_hw_queues(void);
+
 /* Taskpool.numThreads analogue (bls_batch_verifier.nim:316): the number of blinding-scalar hash
  * chains ("virtual threads") B = min(n, num_threads) the parallel path splits a batch into; chunk c
  * is seeded SHA256(rnd || LE64(c)) exactly as processSingleChunk does (:333-336).  Default 4096. */
@@ -99,7 +108,14 @@ int mi355_bls_batch_wait(mi355_bls_ctx* ctx);
  * partition B = min(n_b, num_threads), serial chain for n_b < 3 or num_threads = 1, bls_batch_verifier.nim:440); the union is
  * verified at once, and the product of the k batch checks is one iff every batch verifies (up to the 2^-64 of the random linear
  * combination, the reference's own bound).  If it is not, or if the union exceeds the context's capacity, the batches are
- * verified one by one.  Returns 1 when every batch verified, 0 otherwise, negative on runtime failure. */
+ * verified one by one.  Returns 1 when every batch verified, 0 otherwise, negative on runtime failure.  * REQUIREMENT for the merged pass: the k secureRandomBytes must be pairwise independent.  The library checks what it can: if any two
+ * non-empty batches carry the SAME 32 bytes (their blinding chains would coincide and errors could cancel ACROSS batches, which k
+ * separate calls would not allow), no merged pass is made and the batches are verified one by one - the verdicts stay those of k
+ * separate calls, only the speed-up is lost.  Draw one fresh rnd per batch.
+ * COST: a passing call is one whole-chip pass.  A call in which some batch fails costs that pass PLUS k single-batch calls (about
+ * twice the latency; the calls are synchronous): an adversary who can place one bad signature per call forces the slow path for all
+ * k batches - hosts that expect failures should keep k small or verify suspicious batches separately.
+*/
 int mi355_bls_batch_verify_many(mi355_bls_ctx* ctx, const void* sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[]);
 int mi355_bls_batch_verify_many_device(mi355_bls_ctx* ctx, const void* d_sets, const size_t counts[], const uint8_t* rnds, size_t k, uint8_t verdicts[],
                                        void* stream);
@@ -173,6 +189,12 @@ void mi355_bls_chunk_range(size_t n_total, uint32_t num_threads, uint32_t chunk_
  * caller finishes with blst_p1_to_affine as the reference's `finish` does).  Host or device input. */
 int mi355_bls_g1_aggregate(mi355_bls_ctx* ctx, const void* pks, size_t n, uint8_t out_p1[144]);
 int mi355_bls_g1_aggregate_device(mi355_bls_ctx* ctx, const void* d_pks, size_t n, void* stream, uint8_t out_p1[144]);
+/* aggregateAll on signatures (genAggregatorProcedures(AggregateSignature, Signature, p2), blst_min_pubkey_sig_core.nim:179-195,211):
+ * sigs: n x 192 B blst_p2_affine (infinity = all zero contributes nothing), out_p2: the sum as blst_p2 (Jacobian, 288 B) - what
+ * mi355_bls_aggregate_verify_p2 / mi355_bls_aggv_finish_p2 take.  n == 0: MI355_BLS_ERR_ARG (the reference's openArray form
+ * returns false before touching its output). */
+int mi355_bls_g2_aggregate(mi355_bls_ctx* ctx, const void* sigs, size_t n, uint8_t out_p2[288]);
+int mi355_bls_g2_aggregate_device(mi355_bls_ctx* ctx, const void* d_sigs, size_t n, void* stream, uint8_t out_p2[288]);
 
 /* fastAggregateVerify(publicKeys, message, signature) (bls_sig_min_pubkey.nim:234-258): aggregate the
  * n public keys on the device, then coreVerifyNoGroupCheck (core :269-297): e(agg, H(msg)) == e(G1, sig).
@@ -303,6 +325,10 @@ int mi355_bls_combine(mi355_bls_ctx* ctx, const uint8_t rnd[32], const void* pks
  * context's capacity are processed in slices. */
 int mi355_bls_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n,
                                const void* sig);
+/* the same with the signature as an AggregateSignature (blst_p2, Jacobian, 288 B): finish(signature: AggregateSignature),
+ * blst_min_pubkey_sig_core.nim:357 - converted to affine on the device (blst_p2_to_affine) before the pairing */
+int mi355_bls_aggregate_verify_p2(mi355_bls_ctx* ctx, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n,
+                                  const void* sig_p2);
 
 /* The streaming form, ContextCoreAggregateVerify.init / update / finish (blst_min_pubkey_sig_core.nim:321-414; driven by
  * bls_sig_min_pubkey.nim:127-199 for the AoS and SoA overloads): init resets the context's pair list; update(publicKey,
@@ -313,6 +339,9 @@ int mi355_bls_aggregate_verify(mi355_bls_ctx* ctx, const void* pks, const uint8_
 int mi355_bls_aggv_init(mi355_bls_ctx* ctx);
 int mi355_bls_aggv_update(mi355_bls_ctx* ctx, const void* pk, const uint8_t* msg, size_t msg_len);
 int mi355_bls_aggv_finish(mi355_bls_ctx* ctx, const void* sig);
+/* finish(signature: AggregateSignature) (core :357): sig_p2 = blst_p2, Jacobian, 288 B.  update returns MI355_BLS_ERR_CAPACITY (and
+ * appends nothing) once the collected messages would exceed 4 GiB (offsets are 32-bit). */
+int mi355_bls_aggv_finish_p2(mi355_bls_ctx* ctx, const void* sig_p2);
 
 /* Batch signer / input generator.  Per tuple i, from a 32-byte little-endian secret scalar
  * (blst_scalar image, SecretKey, blst_min_pubkey_sig_core.nim:43-66) and a 32-byte message:

@@ -84,6 +84,9 @@ def lib():
         L.mi355_bls_p2s_mult_pippenger_device.argtypes = [vp, ctypes.c_char_p, vp, sz, vp, sz, vp]
         L.mi355_bls_g1_aggregate.argtypes = [vp, vp, sz, ctypes.c_char_p]
         L.mi355_bls_g1_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
+        L.mi355_bls_g2_aggregate.argtypes = [vp, vp, sz, ctypes.c_char_p]
+        L.mi355_bls_g2_aggregate_device.argtypes = [vp, vp, sz, vp, ctypes.c_char_p]
+        L.mi355_bls_recommend_hw_queues.argtypes = []
         L.mi355_bls_fast_aggregate_verify.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
         L.mi355_bls_fast_aggregate_verify_device.argtypes = [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p, vp]
         L.mi355_bls_fast_aggregate_verify_multi.argtypes = [ctypes.POINTER(vp), sz, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]
@@ -108,6 +111,8 @@ def lib():
         L.mi355_bls_aggv_init.argtypes = [vp]
         L.mi355_bls_aggv_update.argtypes = [vp, cp, cp, sz]
         L.mi355_bls_aggv_finish.argtypes = [vp, cp]
+        L.mi355_bls_aggv_finish_p2.argtypes = [vp, cp]
+        L.mi355_bls_aggregate_verify_p2.argtypes = [vp, cp, cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
         L.mi355_bls_msm_shard_range.argtypes = [sz, u32, u32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mi355_bls_msm_shard_range.restype = None
         L.mi355_bls_p1s_mult_pippenger_multi.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_char_p, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz]
@@ -371,6 +376,20 @@ def aggregateAll(cache, publicKeys):
     return out.raw
 
 
+def aggregateAllSignatures(cache, signatures):
+    """aggregateAll on signatures (genAggregatorProcedures(AggregateSignature, Signature, p2), blst_min_pubkey_sig_core.nim:179-195,211):
+    n x 192-byte affine signatures -> 288-byte blst_p2 (an AggregateSignature).  Empty input -> None (the reference returns false)."""
+    buf = bytes(signatures) if isinstance(signatures, (bytes, bytearray, memoryview)) else b"".join(signatures)
+    if len(buf) % 192:
+        raise ValueError("signatures are 192-byte blst_p2_affine images")
+    n = len(buf) // 192
+    if n == 0:
+        return None
+    out = ctypes.create_string_buffer(288)
+    _check(lib().mi355_bls_g2_aggregate(cache._h, buf, n, out))
+    return out.raw
+
+
 def fastAggregateVerify(cache, publicKeys, message, signature):
     """bls_sig_min_pubkey.nim:234-258.  Empty key list -> False."""
     buf = bytes(publicKeys) if isinstance(publicKeys, (bytes, bytearray, memoryview)) else b"".join(publicKeys)
@@ -572,13 +591,14 @@ def aggregateVerify(cache, publicKeys, messages, signature):
     pks, msgs = list(publicKeys), [bytes(x) for x in messages]
     if len(pks) != len(msgs) or len(pks) == 0:
         return False
-    if any(len(p) != 96 for p in pks) or len(signature) != 192:
-        raise ValueError("public keys are 96-byte, the signature a 192-byte BLST affine image")
+    if any(len(p) != 96 for p in pks) or len(signature) not in (192, 288):
+        raise ValueError("public keys are 96-byte; the signature a 192-byte Signature (affine) or a 288-byte AggregateSignature (blst_p2)")
     offs = [0]
     for x in msgs:
         offs.append(offs[-1] + len(x))
     arr = (ctypes.c_uint32 * len(offs))(*offs)
-    return bool(_check(lib().mi355_bls_aggregate_verify(cache._h, b"".join(pks), b"".join(msgs) or b"\0", arr, len(pks), bytes(signature))))
+    fn = lib().mi355_bls_aggregate_verify if len(signature) == 192 else lib().mi355_bls_aggregate_verify_p2
+    return bool(_check(fn(cache._h, b"".join(pks), b"".join(msgs) or b"\0", arr, len(pks), bytes(signature))))
 
 
 class ContextCoreAggregateVerify:
@@ -598,8 +618,11 @@ class ContextCoreAggregateVerify:
         return bool(_check(lib().mi355_bls_aggv_update(self._c._h, bytes(publicKey), m or None, len(m))))
 
     def finish(self, signature):
+        """finish(signature: Signature or AggregateSignature) (core :357): 192-byte affine or 288-byte Jacobian image"""
+        if len(signature) == 288:
+            return bool(_check(lib().mi355_bls_aggv_finish_p2(self._c._h, bytes(signature))))
         if len(signature) != 192:
-            raise ValueError("the signature is a 192-byte blst_p2_affine image")
+            raise ValueError("the signature is a 192-byte blst_p2_affine or a 288-byte blst_p2 image")
         return bool(_check(lib().mi355_bls_aggv_finish(self._c._h, bytes(signature))))
 
 

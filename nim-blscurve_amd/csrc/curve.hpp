@@ -81,22 +81,36 @@ BLS_HD jac<F> jac_select(bool c, const jac<F>& a, const jac<F>& b) {
     return jac<F>{f_select(c, a.x, b.x), f_select(c, a.y, b.y), f_select(c, a.z, b.z)};
 }
 
+// Who multiplies: the shared out-of-line multiplier bodies (mul_shared: every formula's default), or the bodies expanded in place
+// (mul_inplace: G2 only, see fp2_mul_inl)
+struct mul_shared {
+    template <class F> BLS_HD F mul(const F& a, const F& b) const { return f_mul(a, b); }
+    template <class F> BLS_HD F sqr(const F& a) const { return f_sqr(a); }
+};
+struct mul_inplace {
+    BLS_HD fp2 mul(const fp2& a, const fp2& b) const { return fp2_mul_inl(a, b); }
+    BLS_HD fp2 sqr(const fp2& a) const { return fp2_sqr_inl(a); }
+    BLS_HD fp mul(const fp& a, const fp& b) const { return fp_mul_inl(a, b); }
+    BLS_HD fp sqr(const fp& a) const { return fp_sqr_inl(a); }
+};
 // dbl-2009-l (a = 0): 2M + 5S.  Z = 0 or Y = 0 give Z3 = 0.
-template <class F>
-BLS_MID jac<F> jac_dbl(const jac<F>& p) {
-    F A = f_sqr(p.x);
-    F B = f_sqr(p.y);
-    F C = f_sqr(B);
-    F D = f_carry(f_dbl_nc(f_sub_nc(f_sub_nc(f_sqr(f_add(p.x, B)), A), C)));     // 6 limb units, one carry
+template <class F, class M>
+BLS_MID jac<F> jac_dbl_m(const jac<F>& p, const M& m) {
+    F A = m.sqr(p.x);
+    F B = m.sqr(p.y);
+    F C = m.sqr(B);
+    F D = f_carry(f_dbl_nc(f_sub_nc(f_sub_nc(m.sqr(f_add(p.x, B)), A), C)));     // 6 limb units, one carry
     F E = f_carry(f_add_nc(f_dbl_nc(A), A));
-    F Fq = f_sqr(E);
+    F Fq = m.sqr(E);
     jac<F> r;
     r.x = f_red(f_sub_nc(Fq, f_dbl_nc(D)));
     F C8 = f_dbl_nc(f_carry(f_dbl_nc(f_dbl_nc(C))));
-    r.y = f_carry(f_sub_nc(f_mul(E, f_sub_nc(D, r.x)), C8));     // y, z: carried only (|y| < 19p, |z| < 5p)
-    r.z = f_carry(f_dbl_nc(f_mul(p.y, p.z)));
+    r.y = f_carry(f_sub_nc(m.mul(E, f_sub_nc(D, r.x)), C8));     // y, z: carried only (|y| < 19p, |z| < 5p)
+    r.z = f_carry(f_dbl_nc(m.mul(p.y, p.z)));
     return r;
 }
+template <class F>
+BLS_MID jac<F> jac_dbl(const jac<F>& p) { return jac_dbl_m(p, mul_shared{}); }
 
 // Lane-cooperative doubling for latency-bound chains (one point, or a few, and a whole wave to spend): a TEAM of lanes that all
 // hold the same point computes the independent products of each round of dbl-2009-l in ONE multiplier call, every lane taking

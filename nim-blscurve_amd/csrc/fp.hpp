@@ -87,7 +87,7 @@ BLS_HD fp fp_from_const(const uint32_t (&c)[FP_N]) {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = c[i];
     BLS_SET_VB(r, 1);
-    BLS_SET_LB(r, 1);
+    BLS_SET_LB(r, 0);        // the generated constants are canonical: limbs 0..12 in [0, 2^28)
     return r;
 }
 
@@ -96,7 +96,7 @@ BLS_HD fp fp_zero() {
 #pragma unroll
     for (int i = 0; i < FP_N; i++) r.l[i] = 0;
     BLS_SET_VB(r, 1);
-    BLS_SET_LB(r, 1);
+    BLS_SET_LB(r, 0);
     return r;
 }
 
@@ -297,6 +297,76 @@ BLS_HD fp fp_dot2_core(const fp& a, const fp& b, const fp& c, const fp& d) {
     BLS_SET_VB(r, 2);
     BLS_SET_LB(r, 0);
     return r;
+}
+
+// Montgomery dot product (sum_t x_t * y_t) * 2^-392 mod p of N pairs with ONE reduction: 196 N operand multiply-adds + 196 for the
+// reduction (the general form of fp_dot2_core).  What a sum of products costs in THIS machine is its instruction count (every VALU
+// instruction takes the same issue slot at one wave per SIMD), and a reduction is 196 multiply-adds + 68 bookkeeping instructions
+// plus whatever additions, subtractions and carry steps combine separately reduced products afterwards: a schoolbook sum with one
+// reduction per output coefficient beats a Karatsuba tree of separately reduced products wherever the tree's glue is heavy
+// (fp12_mul_by_line_lazy: 12 of these instead of 13 Fp2 products, 26 reductions and ~1 500 instructions of glue).
+// Column bound: sum_t |x_t limb| |y_t limb| * 14 + 14 * 2^56 + carry < 2^63, i.e. sum_t lb(x_t) lb(y_t) <= 8 limb units (2^28 each,
+// with the usual 2^20 of slack per limb); value bound: sum_t vb(x_t) vb(y_t) <= 2048.  Result in (-2p, 2p), canonical limbs.
+template <int N>
+BLS_HD fp fp_dotn_core(const fp (&x)[N], const fp (&y)[N]) {
+    int64_t acc = 0;
+    int32_t m[FP_N];
+    fp r;
+#pragma unroll
+    for (int kk = 0; kk < FP_N; kk++) {
+#pragma unroll
+        for (int t = 0; t < N; t++) {
+#pragma unroll
+            for (int i = 0; i <= kk; i++) acc = bls_mac(acc, (int32_t)x[t].l[i], (int32_t)y[t].l[kk - i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kk; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
+        m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
+        acc = bls_mac_c(acc, m[kk], k::P[0]);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
+#pragma unroll
+        for (int t = 0; t < N; t++) {
+#pragma unroll
+            for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac(acc, (int32_t)x[t].l[i], (int32_t)y[t].l[kk - i]);
+        }
+#pragma unroll
+        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
+        r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
+        acc >>= 28;
+    }
+    r.l[FP_N - 1] = (uint32_t)acc;
+    BLS_SET_VB(r, 2);
+    BLS_SET_LB(r, 0);
+    return r;
+}
+// checked form (host: bounds tracker + census; device: the core in place)
+template <int N>
+BLS_HD fp fp_dotn(const fp (&x)[N], const fp (&y)[N]) {
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+    uint64_t vsum = 0, lsum = 0;
+    const int64_t LIM1 = (1ll << 28) + (1ll << 20);
+    for (int t = 0; t < N; t++) {
+        vsum += (uint64_t)BLS_VB(x[t]) * BLS_VB(y[t]);
+        int64_t mx = 0, my = 0;                       // measured magnitudes must fit the DECLARED limb units
+        for (int i = 0; i < FP_N; i++) {
+            int64_t a = (int32_t)x[t].l[i], b = (int32_t)y[t].l[i];
+            if (a < 0) a = -a;
+            if (b < 0) b = -b;
+            if (a > mx) mx = a;
+            if (b > my) my = b;
+        }
+        uint64_t lx = BLS_LB(x[t]) ? BLS_LB(x[t]) : 1, ly = BLS_LB(y[t]) ? BLS_LB(y[t]) : 1;
+        BLS_REQUIRE(mx < (int64_t)lx * LIM1 && my < (int64_t)ly * LIM1, "fp_dotn limb magnitude exceeds its declared units");
+        lsum += lx * ly;
+    }
+    BLS_REQUIRE(vsum <= 2048, "fp_dotn value bounds");
+    BLS_REQUIRE(lsum <= 8, "fp_dotn limb-unit bounds (column sum)");
+#endif
+    BLS_COUNT_MADS(196 * N + 196);
+    return fp_dotn_core<N>(x, y);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -859,6 +929,26 @@ BLS_HD fp2 fp2_mul(const fp2& a, const fp2& b) {
 BLS_HD fp2 fp2_sqr(const fp2& a) {
     return fp2{fp_mul(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1)), fp_mul(fp_dbl_nc(a.c0), a.c1)};
 }
+#endif
+
+// The same two operations with the multiplier bodies expanded IN PLACE (device: no call, no argument moves, no LDS hand-over of the
+// second operand; ~1 350 / ~960 instructions of code per use): for the few loops whose whole body may be this large - the doubling
+// runs of the cofactor clearing, where an out-of-line call costs 56 register moves per product and keeps the loop-carried point out
+// of the multiplier's registers.  Host: the checked out-of-line forms (same arithmetic, same census).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ fp2 fp2_mul_inl(const fp2& a, const fp2& b) {
+    return fp2{fp_dot2_core(a.c0, b.c0, fp_neg(a.c1), b.c1), fp_dot2_core(a.c0, b.c1, a.c1, b.c0)};
+}
+__device__ __forceinline__ fp2 fp2_sqr_inl(const fp2& a) {
+    return fp2{fp_mul_core(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1)), fp_mul_core(fp_dbl_nc(a.c0), a.c1)};
+}
+__device__ __forceinline__ fp fp_mul_inl(const fp& a, const fp& b) { return fp_mul_core(a, b); }
+__device__ __forceinline__ fp fp_sqr_inl(const fp& a) { return fp_sqr_core(a); }
+#else
+BLS_HD fp2 fp2_mul_inl(const fp2& a, const fp2& b) { return fp2_mul(a, b); }
+BLS_HD fp2 fp2_sqr_inl(const fp2& a) { return fp2_sqr(a); }
+BLS_HD fp fp_mul_inl(const fp& a, const fp& b) { return fp_mul(a, b); }
+BLS_HD fp fp_sqr_inl(const fp& a) { return fp_sqr(a); }
 #endif
 
 BLS_HD fp2 fp2_mul_fp(const fp2& a, const fp& b) { return fp2{fp_mul(a.c0, b), fp_mul(a.c1, b)}; }

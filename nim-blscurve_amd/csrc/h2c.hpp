@@ -224,28 +224,45 @@ struct g2_park_regs {
 
 // h_eff clearing, RFC 9380 appendix G.3 (Budroni-Pintore): [x^2 - x - 1]P + [x - 1]psi(P) + psi^2(2P)
 //   = psi^2(2P) - psi(P) - [x]P - P  +  [x]([x]P + psi(P))
-// written as ONE copy of the 63-doubling chain executed twice (pass 0: t1 = [x]P; pass 1: [x](t1 + psi(P))), with the chain's
-// accumulator a plain loop-carried value: inlined into the kernel it lives in registers for the whole chain (as the return
-// value of an out-of-line [x]-multiplication it lived in scratch memory and was stored back 84 words per doubling).
-// dbl: the doubling of the chain (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
+// written as ONE copy of the 63-doubling chain executed twice (pass 0: t1 = [x]P; pass 1: [x](t1 + psi(P))).
+// |x| = 0xd201000000010000 has six set bits, so the chain is six RUNS of consecutive doublings (1, 2, 3, 9, 32, 16) with an addition
+// of the base point between them.  A run is ONE call dbl_run(acc, n): the accumulator of a run is a loop-carried value inside that
+// function and stays in registers for the whole run.  (Round 3 called a doubling functor once per doubling; hipcc kept that functor
+// out of line - two call sites, 8 400 instructions - so the accumulator went through scratch memory on the way in and on the way
+// out of EVERY doubling: four dependent memory passes of 84 words per doubling at one wave per SIMD, i.e. with nothing to hide them:
+// 10 % of k_hash_clear's wave cycles were s_waitcnt.  Now it crosses memory 8 times per pass instead of 64.)
+// dbl_run: n >= 1 doublings (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
 // add_in: the additions inside the chain (accumulator + parked base); add: the others.  The one-lane-per-point kernels pass the
 // inlined body / the out-of-line addition, the kernels with a team of lanes per point the lane-cooperative jac_add_team.
-template <class Pt, class Park, class Dbl, class AddIn, class Add>
-BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl, AddIn&& add_in, Add&& add) {
+#ifndef BLS_CLEAR_MUL
+#define BLS_CLEAR_MUL mul_inplace            // A/B switch: -DBLS_CLEAR_MUL=mul_shared calls the shared multiplier bodies instead
+#endif
+// dbl_run has exactly ONE call site here (the loop over the runs), so that a caller may force it inline: inside a kernel the
+// accumulator is then a plain SSA value.  (Out of line, its loop-carried point lives in the function's return slot, i.e. in scratch
+// memory, and is stored and re-loaded around every doubling all the same.)  dbl1: one doubling, for 2P (not on the hot path).
+template <class Pt, class Park, class DblRun, class Dbl1, class AddIn, class Add>
+BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, DblRun&& dbl_run, Dbl1&& dbl1, AddIn&& add_in, Add&& add) {
     Pt base = p, u = p, res = p;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < 2; pass++) {
         park.put(base);
         Pt acc = base;                                       // bit 63 of |x|
+        uint64_t rest = k::X_ABS & ~(1ull << 63);            // set bits still to come
+        int pos = 63;
 #pragma clang loop unroll(disable)
-        for (int i = 62; i >= 0; i--) {
-            acc = dbl(acc);
-            if ((k::X_ABS >> i) & 1) acc = add_in(acc, park.get());
+        while (pos > 0) {
+            const int next = rest ? 63 - __builtin_clzll(rest) : 0;
+            acc = dbl_run(acc, pos - next);                  // the one call site
+            if (rest) {
+                acc = add_in(acc, park.get());
+                rest &= ~(1ull << next);
+            }
+            pos = next;
         }
         acc = jac_neg(acc);                                  // x < 0
         if (pass == 0) {
             Pt t2 = g2_psi(p);
-            u = add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));                // psi^2(2P) - psi(P)
+            u = add(g2_psi(g2_psi(dbl1(p))), jac_neg(t2));               // psi^2(2P) - psi(P)
             u = add(u, jac_neg(acc));                                    // - [x]P
             u = add(u, jac_neg(p));                                      // - P
             base = add(acc, t2);                                         // [x]P + psi(P)
@@ -255,17 +272,30 @@ BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl, AddIn&& ad
     }
     return res;
 }
-template <class Pt, class Park, class Dbl>
-BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, Dbl&& dbl) {
-    return clear_cofactor_g2_with(p, park, dbl, [](const Pt& a, const Pt& b) { return jac_add_body(a, b); }, [](const Pt& a, const Pt& b) { return jac_add(a, b); });
+// n >= 1 doublings with the point as a loop-carried value; ONE copy of the doubling in the loop (do-while: no peeled first iteration)
+template <class F, class M>
+BLS_MID jac<F> jac_dbl_n(const jac<F>& a, int n, const M& m) {
+    jac<F> r = a;
+#pragma clang loop unroll(disable)
+    do {
+        r = jac_dbl_m(r, m);
+    } while (--n > 0);
+    return r;
 }
-template <class Park>
-BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park) {
-    return clear_cofactor_g2_with(p, park, [](const g2_jac& a) { return jac_dbl(a); });
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BLS_LAMBDA_INLINE __attribute__((always_inline))
+#else
+#define BLS_LAMBDA_INLINE
+#endif
+template <class Park, class M>
+BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park, const M& m) {
+    return clear_cofactor_g2_with(
+        p, park, [&](const g2_jac& a, int n) BLS_LAMBDA_INLINE { return jac_dbl_n(a, n, m); }, [](const g2_jac& a) { return jac_dbl(a); },
+        [](const g2_jac& a, const g2_jac& b) { return jac_add_body(a, b); }, [](const g2_jac& a, const g2_jac& b) { return jac_add(a, b); });
 }
 BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
     g2_park_regs park;
-    return clear_cofactor_g2_with(p, park);
+    return clear_cofactor_g2_with(p, park, mul_shared{});
 }
 
 BLS_HDN g2_jac hash_to_g2(const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {

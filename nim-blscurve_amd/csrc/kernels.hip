@@ -18,6 +18,7 @@
 // loads/stores of one limb group are contiguous across the wave (coalesced dwordx4).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
 #else
     g2_park_regs park;               // host pass of the translation unit: kernels are parsed, never run
 #endif
-    soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park));
+    soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park, BLS_CLEAR_MUL{}));
 }
 
 // arbitrary-length message (fastAggregateVerify / coreVerify shape): ONE message, so latency is all that matters.
@@ -426,7 +427,15 @@ __device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32
     g2_park_regs park;
     team_lanes8 team{gbase, role};
     auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
-    return clear_cofactor_g2_with(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
+    auto dbl_run = [&](const g2_jac& a, int n) {
+        g2_jac r = a;
+#pragma clang loop unroll(disable)
+        do {
+            r = jac_dbl_team(r, team);
+        } while (--n > 0);
+        return r;
+    };
+    return clear_cofactor_g2_with(p, park, dbl_run, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
 }
 __device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
@@ -523,12 +532,39 @@ __global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, con
     });
 }
 
+// The per-lane accumulation loop of k_lineprod as ONE hand-allocated assembly statement (tools/gen_lineprod_asm.py, written to
+// build/lineprod_asm.inc by build.sh): f <- line_0, then f <- f * line_j for j = 1 .. rounds - 1 with fp12_mul_by_line_lazy's schoolbook
+// product (two six-term Montgomery dot products per coefficient), every value in a fixed register, no scratch, no LDS, no calls;
+// lanes whose pair index is past npairs sit out (exec) and keep f = 1.  The statement ends with f stored in st_fp12_int's layout.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LINEPROD_NOASM)
+#include "../build/lineprod_asm.inc"
+__device__ __forceinline__ void lineprod_asm(const uint4* step_base, uint32_t stride16, uint32_t npairs, uint32_t first, uint32_t rounds, uint32_t* out,
+                                             uint32_t lds_buf) {
+    asm volatile(BLS_LINEPROD_ASM_BODY : : "s"(step_base), "s"(stride16), "s"(npairs), "s"(first), "s"(rounds), "s"(out), "s"(lds_buf) : BLS_LINEPROD_ASM_CLOBBERS);
+}
+#endif
 // grid (N_LINES, nblk): block b of step s multiplies lines of pairs b*64*m .. (b+1)*64*m
 __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lines, uint32_t npairs, size_t stride, uint32_t m,
                                                    uint32_t* __restrict__ part, uint32_t nblk, int per_lane) {
     uint32_t s = blockIdx.x, b = blockIdx.y;
     const uint4* base = lines + (size_t)s * 24 * stride;
     size_t first = (size_t)b * WAVE * m;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 line_slots[4 * BLS_LDS_SLOT];              // 28 KB: with the 7 KB hand-over slot 35 of the 40 KB a wave may use
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LINEPROD_NOASM)
+    if (per_lane == 1) {                              // wave-uniform; 2 = the compiled per-lane path below (byte offsets beyond 32 bits)
+        uint32_t rounds = 0;
+        if (first < npairs) {
+            size_t left = (npairs - first + WAVE - 1) / WAVE;
+            rounds = left < m ? (uint32_t)left : m;
+        }
+        // the next line travels HBM -> LDS (LDS-DMA, 24 rows of 1 KiB) while the current one is multiplied: the same 28 KiB the compiled path parks its line in
+        lineprod_asm(base, (uint32_t)(stride * 16), npairs, (uint32_t)first, rounds, part + ((size_t)s * nblk + b) * WAVE * F12W,
+                     (uint32_t)(uintptr_t)(bls_lds_u32x4*)line_slots);
+        return;
+    }
+#endif
     // Straight-line accumulation (no "have a value yet" flag, no per-lane conditional update: those made the
     // compiler keep f in scratch memory across iterations).  Lanes past the end multiply by the line 1; a round
     // with no valid lane at all ends the loop (wave-uniform test).
@@ -541,17 +577,17 @@ __global__ void __launch_bounds__(WAVE) k_lineprod(const uint4* __restrict__ lin
     };
     fp12 f = fp12_one();
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ bls_u32x4 line_slots[4 * BLS_LDS_SLOT];              // 28 KB: with the 7 KB hand-over slot 35 of the 40 KB a wave may use
     line_ops_lds lops{(bls_lds_u32x4*)line_slots};
 #else
     line_ops_lds lops{};
 #endif
     if (first < npairs) {
         f = fp12_from_line(ld_line(first));
+#pragma clang loop unroll(disable)
         for (uint32_t j = 1; j < m; j++) {
             size_t j0 = first + (size_t)j * WAVE;
             if (j0 >= npairs) break;
-            lops.park(ld_line(j0));
+            lops.park(ld_line(j0));                  // the compiled path keeps the compact Karatsuba form on the shared multiplier bodies
             f = fp12_mul_by_line_ops(f, lops);
         }
     }
@@ -1677,9 +1713,15 @@ constexpr size_t SIG_WIDE_MIN = 40000;       // from here 8-bit digits (2048 ext
 
 // HIP spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue run strictly in turn: a host
 // with many SMALL batches in flight (one context + stream each) gets 1.4 M verifications/s with 4 queues and 2.3 M/s with 8
-// (tests/gpu_probe_small.py; more than 8 abort in the runtime).  The variable is read when the HIP runtime initialises, so the library
-// sets the default at load time - only if the host has not set it - which takes effect when the library is loaded before the first HIP call.
-__attribute__((constructor)) static void mi355_bls_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (tests/gpu_probe_small.py; more than 8 abort in the runtime).  The variable is read when the HIP runtime initialises.  The library
+// does NOT touch the process environment on its own (round 3 did, from a load-time constructor: setenv is not thread-safe, it changed
+// queue behaviour for every HIP user of the process, and it silently did nothing when HIP was already up): the host sets
+// GPU_MAX_HW_QUEUES=8 itself, or calls this ONCE, from its main thread, before anything initialises HIP.
+extern "C" int mi355_bls_recommend_hw_queues(void) {
+    const char* no = getenv("MI355_BLS_NO_ENV");
+    if (no && no[0] == '1') return 0;                             // the host forbids environment edits
+    return setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0 ? 1 : 0;       // 0 = overwrite flag: a value the host has set stays
+}
 
 static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   // bls_sig_min_pubkey.nim:31
 
@@ -1749,7 +1791,7 @@ static int ctx_build(mi355_bls_ctx* c, int device, size_t max_sets) {
     ALLOC(c->d_sig_consts, 2 * SIG_SLOTS_MAX * G1W * 4);
     ALLOC(c->d_agg, 288);
     ALLOC(c->d_agg1, 144);
-    ALLOC(c->d_msg, 4096 + 192);
+    ALLOC(c->d_msg, 4096 + 192 + 64 + 288);      // message | affine signature | pad | Jacobian signature (AggregateSignature overloads)
     ALLOC(c->d_comp, max_sets * 320);          // wire-format staging: keys (<= 96 B) | messages (32 B) | signatures (<= 192 B)
     ALLOC(c->d_status, max_sets);
     ALLOC(c->d_lpart, (size_t)N_LINES * (c->nblk_cap * (WAVE + 1) + 64) * F12W * 4);     // per-lane partial products of k_lineprod (+ k_fold's first-level results)
@@ -1812,17 +1854,28 @@ static int io_reserve(mi355_bls_ctx* c, size_t n) {
     }
     size_t want = n + n / 4;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipDeviceSynchronize());
-    void** bufs[] = {(void**)&c->d_sets, (void**)&c->d_comp, (void**)&c->d_status, (void**)&c->d_r};
-    for (void** b : bufs) {
-        if (*b) (void)hipFree(*b);
-        *b = nullptr;
+    // the new buffers first: if one allocation fails the context keeps its old buffers and capacity (entry points that take
+    // device-resident input never come through here and would otherwise launch on null pointers)
+    void* nb[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[4] = {want * 320, want * 320, want, (want > c->stride ? want : c->stride) * 8};
+    for (int i = 0; i < 4; i++) {
+        hipError_t e = hipMalloc(&nb[i], bytes[i]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipFree(nb[j]);
+            g_err = std::string("io_reserve: hipMalloc: ") + hipGetErrorString(e);
+            return MI355_BLS_ERR_HIP;
+        }
     }
-    c->cap_io = 0;
-    HIPCHK(hipMalloc((void**)&c->d_sets, want * 320));
-    HIPCHK(hipMalloc((void**)&c->d_comp, want * 320));
-    HIPCHK(hipMalloc((void**)&c->d_status, want));
-    HIPCHK(hipMalloc((void**)&c->d_r, (want > c->stride ? want : c->stride) * 8));
+    // only this context's own work can still read the old buffers, and no call is pending (checked above; blocking calls return after
+    // their stream has drained): the fork stream and the stream of the last call are waited for, never the whole device (other
+    // contexts keep running)
+    if (c->side) HIPCHK(hipStreamSynchronize(c->side));
+    if (c->pending_stream) HIPCHK(hipStreamSynchronize(c->pending_stream));
+    void** bufs[] = {(void**)&c->d_sets, (void**)&c->d_comp, (void**)&c->d_status, (void**)&c->d_r};
+    for (int i = 0; i < 4; i++) {
+        if (*bufs[i]) (void)hipFree(*bufs[i]);
+        *bufs[i] = nb[i];
+    }
     c->cap_io = want;
     return 0;
 }
@@ -1930,7 +1983,9 @@ static int enqueue_line_products(mi355_bls_ctx* c, uint32_t npairs, hipStream_t 
     // every lane hands its partial product over (64 x nblk per step).  Throughput mode: k_lineprod2's 68 waves fold them,
     // 15 sequential Fp12 products per lane + one shuffle tree (least total work); latency mode: k_fold on the lane-cooperative
     // engine, 64 per block and then the nblk block results (one caller, 65 536 tuples: 1.8 -> 0.35 ms)
-    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, 1);
+    // 1: the assembly loop (32-bit byte offsets inside one step's 24 planes); 2: the compiled loop
+    const int per_lane = (uint64_t)c->stride * 16 * 24 + (uint64_t)npairs * 16 < (1ull << 32) ? 1 : 2;
+    k_lineprod<<<dim3(N_LINES, nblk), WAVE, 0, st>>>(c->d_lines, npairs, c->stride, m, c->d_lpart, nblk, per_lane);
     if (mid_ev) HIPCHK(hipEventRecord(mid_ev, st));
     if (c->coop) {
         size_t first_last = (size_t)(nblk - 1) * WAVE * m;             // lanes past the last pair hold 1: not folded
@@ -2211,7 +2266,22 @@ static int verify_many(mi355_bls_ctx* c, const uint8_t* d_src, const uint8_t* h_
     if (total == 0) return 0;                                     // every batch empty: every verdict false (bls_batch_verifier.nim:137-139)
     HIPCHK(hipSetDevice(c->device));
     bool merged_ok = false;
-    if (total <= c->cap && k <= 65536) {
+    // The merged check is sound only if the batches' blinding scalars are independent.  They are a deterministic SHA-256 chain of
+    // (rnd_b, chain id): two batches with the SAME secureRandomBytes and the same count get identical r_i at identical indices, and a
+    // forger who knows that can make errors cancel across them (sig + D at index i of one, sig' - D at index i of the other: the
+    // merged product is 1, both verdicts would be true, while k separate calls reject both).  A host that reuses one rnd for all its
+    // batches is a plausible mistake and harmless with separate calls, so it must be harmless here: any two equal rnds among the
+    // non-empty batches -> no merged pass, the batches are verified one by one.
+    bool rnds_distinct = true;
+    {
+        std::vector<const uint8_t*> rs;
+        for (size_t b = 0; b < k; b++)
+            if (counts[b]) rs.push_back(rnds + 32 * b);
+        std::sort(rs.begin(), rs.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
+        for (size_t i = 1; i < rs.size(); i++)
+            if (memcmp(rs[i - 1], rs[i], 32) == 0) rnds_distinct = false;
+    }
+    if (rnds_distinct && total <= c->cap && k <= 65536) {
         // ---- merged pass
         std::vector<many_meta> meta;
         std::vector<uint8_t> rr;
@@ -2515,6 +2585,9 @@ static std::mutex g_default_mu;
 static mi355_bls_ctx* g_default_ctx = nullptr;
 static int default_ctx_locked(size_t need_sets, mi355_bls_ctx** out) {
     if (need_sets < 1024) need_sets = 1024;
+    // every entry point is capacity-free (a larger batch runs in slices, run_shard), so the default context never grows beyond two
+    // whole-chip batches: mi355_bls_batch_verify_once on 2^20 sets allocates ~4 GB of workspace, not ~30
+    if (need_sets > 131072) need_sets = 131072;
     if (g_default_ctx && g_default_ctx->cap >= need_sets) {
         *out = g_default_ctx;
         return 0;
@@ -2605,6 +2678,50 @@ extern "C" int mi355_bls_last_timings(mi355_bls_ctx* c, float out[8]) {
 // ------------------------------------------------------------------------------------------
 // aggregateAll / fastAggregateVerify
 // ------------------------------------------------------------------------------------------
+// aggregateAll on signatures (genAggregatorProcedures(AggregateSignature, Signature, p2), blst_min_pubkey_sig_core.nim:179-195,211):
+// the same two-level sum over blst_p2_affine inputs (192 B), blst_p2 image out (288 B)
+__global__ void __launch_bounds__(WAVE) k_g2_sum(const uint8_t* __restrict__ pts, uint32_t n, uint32_t m, uint32_t* __restrict__ part) {
+    uint32_t lane0 = blockIdx.x * WAVE + threadIdx.x, strideL = gridDim.x * WAVE;
+    g2_jac acc = jac_inf<fp2>();
+#pragma clang loop unroll(disable)
+    for (uint32_t j = 0; j < m; j++) {
+        uint32_t i = lane0 + j * strideL;
+        if (i < n) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + (size_t)i * 192);
+            acc = jac_add(acc, jac_from_aff(ld_g2a_blst(w)));
+        }
+    }
+#pragma clang loop unroll(disable)
+    for (int d = 32; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) st_g2_int(part + (size_t)blockIdx.x * G2W, acc);
+}
+__global__ void __launch_bounds__(WAVE) k_g2_sum2(const uint32_t* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ out) {
+    g2_jac acc = jac_inf<fp2>();
+#pragma clang loop unroll(disable)
+    for (uint32_t j = threadIdx.x; j < nparts; j += WAVE) acc = jac_add(acc, ld_g2_int(part + (size_t)j * G2W));
+#pragma clang loop unroll(disable)
+    for (int d = 32; d >= 1; d >>= 1) {
+        g2_jac o = shfl_down_struct(acc, d);
+        acc = jac_add(acc, o);
+    }
+    if (threadIdx.x == 0) st_g2_blst(out, acc);        // blst_p2 image
+}
+// one blst_p2 (Jacobian, 288 B) -> blst_p2_affine (192 B; infinity = all zero): finish(AggregateSignature) converts like this
+// before the pairing (blst_min_pubkey_sig_core.nim:357-360: blst_p2_to_affine)
+__global__ void k_p2_to_affine(const uint32_t* __restrict__ p2, uint32_t* __restrict__ out_sig) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g2_jac b = ld_g2_blst(p2);
+    if (jac_is_inf(b)) {
+        for (int i = 0; i < 48; i++) out_sig[i] = 0;
+    } else {
+        fp2 zi = fp2_inv(fp2_reduce(b.z)), zi2 = fp2_sqr(zi);
+        fp2 x = fp2_mul(b.x, zi2), y = fp2_mul(b.y, fp2_mul(zi2, zi));
+        st_fp_blst(out_sig, x.c0); st_fp_blst(out_sig + 12, x.c1); st_fp_blst(out_sig + 24, y.c0); st_fp_blst(out_sig + 36, y.c1);
+    }
+}
 static int g1_sum_enqueue(mi355_bls_ctx* c, const uint8_t* d_pts, size_t n, hipStream_t st) {
     // result (blst_p1 image, 144 B) lands in d_agg1
     uint32_t n32 = (uint32_t)n;
@@ -2634,6 +2751,38 @@ extern "C" int mi355_bls_g1_aggregate_device(mi355_bls_ctx* c, const void* d_pks
     return 0;
 }
 
+extern "C" int mi355_bls_g2_aggregate_device(mi355_bls_ctx* c, const void* d_sigs, size_t n, void* stream, uint8_t out_p2[288]) {
+    if (!c || !d_sigs || !out_p2 || n == 0 || n > (1u << 30)) return MI355_BLS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    uint32_t n32 = (uint32_t)n;
+    uint32_t nblk = (n32 + WAVE * 8 - 1) / (WAVE * 8);          // ~8 points per lane
+    if (nblk > c->slots) nblk = c->slots;
+    if (nblk > 2048) nblk = 2048;                               // d_export holds 2048 x 2 G1-sized partials beside its export area
+    if (nblk < 1) nblk = 1;
+    uint32_t m = (n32 + nblk * WAVE - 1) / (nblk * WAVE);
+    k_g2_sum<<<nblk, WAVE, 0, st>>>((const uint8_t*)d_sigs, n32, m, c->d_export);
+    k_g2_sum2<<<1, WAVE, 0, st>>>(c->d_export, nblk, c->d_agg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipMemcpyAsync(out_p2, c->d_agg, 288, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) c->timings[i] = 0;
+    HIPCHK(hipEventElapsedTime(&c->timings[0], c->ev[0], c->ev[1]));
+    c->timings[7] = c->timings[0];
+    return 0;
+}
+extern "C" int mi355_bls_g2_aggregate(mi355_bls_ctx* c, const void* sigs, size_t n, uint8_t out_p2[288]) {
+    if (!c || !sigs || !out_p2 || n == 0) return MI355_BLS_ERR_ARG;
+    {
+        int rcr = io_reserve(c, (n * 192 + 319) / 320);
+        if (rcr) return rcr;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_sets, sigs, n * 192, hipMemcpyHostToDevice, nullptr));
+    return mi355_bls_g2_aggregate_device(c, c->d_sets, n, nullptr, out_p2);
+}
 extern "C" int mi355_bls_g1_aggregate(mi355_bls_ctx* c, const void* pks, size_t n, uint8_t out_p1[144]) {
     if (!c || !pks || !out_p1 || n == 0) return MI355_BLS_ERR_ARG;
     {
@@ -3315,7 +3464,7 @@ static int aggv_slice(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs,
 
 // Any number of pairs: more than the context's capacity (pairs, or staged bytes: keys + offsets + messages share d_sets) are
 // processed in slices whose committed states are multiplied on the engine (k_state_mul), as for batchVerify.
-extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig) {
+static int aggregate_verify_impl(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig, bool sig_is_p2) {
     if (!c || !sig) return MI355_BLS_ERR_ARG;
     if (n == 0) return 0;                                   // "Spec precondition" (bls_sig_min_pubkey.nim:165-167)
     if (!pks || !msgs || !msg_offsets) return MI355_BLS_ERR_ARG;
@@ -3324,7 +3473,12 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = nullptr;
     HIPCHK(hipMemsetAsync(c->d_flags, 0, 12, st));
-    HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
+    if (sig_is_p2) {                                        // AggregateSignature (blst_p2, Jacobian): to affine on the device, as finish() does
+        HIPCHK(hipMemcpyAsync(c->d_msg + 4096 + 256, sig, 288, hipMemcpyHostToDevice, st));
+        k_p2_to_affine<<<1, 1, 0, st>>>(reinterpret_cast<const uint32_t*>(c->d_msg + 4096 + 256), reinterpret_cast<uint32_t*>(c->d_msg + 4096));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_msg + 4096, sig, 192, hipMemcpyHostToDevice, st));
+    }
     const size_t budget = c->cap * 320;
     std::vector<uint32_t> offs;
     size_t a = 0;
@@ -3373,6 +3527,14 @@ extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, con
     return (fl[0] == 0 && fl[1] == 1) ? 1 : 0;
 }
 
+extern "C" int mi355_bls_aggregate_verify(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig) {
+    return aggregate_verify_impl(c, pks, msgs, msg_offsets, n, sig, false);
+}
+// the same with the signature as an AggregateSignature (blst_p2, Jacobian, 288 B): finish(AggregateSignature), core :357
+extern "C" int mi355_bls_aggregate_verify_p2(mi355_bls_ctx* c, const void* pks, const uint8_t* msgs, const uint32_t* msg_offsets, size_t n, const void* sig_p2) {
+    return aggregate_verify_impl(c, pks, msgs, msg_offsets, n, sig_p2, true);
+}
+
 // ContextCoreAggregateVerify (blst_min_pubkey_sig_core.nim:305-414), the streaming form: init / update(publicKey, message) /
 // finish(signature).  The pairs are collected on the host (176 bytes + the message each) and verified by ONE device call at
 // finish - the reference's update also only queues work that commit / finalVerify later complete (blst's N_MAX = 8 pair buffer).
@@ -3395,25 +3557,32 @@ extern "C" int mi355_bls_aggv_update(mi355_bls_ctx* c, const void* pk, const uin
         c->av_failed = true;
         return 0;
     }
+    if (c->av_msgs.size() + msg_len > 0xffffffffull) {   // message offsets are 32-bit: refuse instead of wrapping (the context stays usable)
+        g_err = "mi355_bls_aggv_update: more than 4 GiB of messages in one aggregateVerify";
+        return MI355_BLS_ERR_CAPACITY;
+    }
     c->av_pks.insert(c->av_pks.end(), p, p + 96);
     if (msg_len) c->av_msgs.insert(c->av_msgs.end(), msg, msg + msg_len);
     c->av_offs.push_back((uint32_t)c->av_msgs.size());
     return 1;
 }
-extern "C" int mi355_bls_aggv_finish(mi355_bls_ctx* c, const void* sig) {
+static int aggv_finish_impl(mi355_bls_ctx* c, const void* sig, bool sig_is_p2) {
     if (!c || !sig || c->av_offs.empty()) return MI355_BLS_ERR_ARG;
     size_t n = c->av_offs.size() - 1;
     int rc = 0;
     // no pair seen: blst's finalverify has no GT accumulator set -> false; a failed update -> false
     if (!c->av_failed && n) {
         uint8_t dummy = 0;
-        rc = mi355_bls_aggregate_verify(c, c->av_pks.data(), c->av_msgs.empty() ? &dummy : c->av_msgs.data(), c->av_offs.data(), n, sig);
+        rc = aggregate_verify_impl(c, c->av_pks.data(), c->av_msgs.empty() ? &dummy : c->av_msgs.data(), c->av_offs.data(), n, sig, sig_is_p2);
     }
     c->av_offs.clear();                                  // finish consumes the context: init again before the next use
     c->av_pks.clear();
     c->av_msgs.clear();
     return rc;
 }
+extern "C" int mi355_bls_aggv_finish(mi355_bls_ctx* c, const void* sig) { return aggv_finish_impl(c, sig, false); }
+// finish(signature: AggregateSignature) (blst_min_pubkey_sig_core.nim:357): the Jacobian blst_p2 image, 288 B
+extern "C" int mi355_bls_aggv_finish_p2(mi355_bls_ctx* c, const void* sig_p2) { return aggv_finish_impl(c, sig_p2, true); }
 
 // ------------------------------------------------------------------------------------------
 // Point-sharded MSM across devices ("MSM"): every device computes the full-width partial sum of its

@@ -51,24 +51,27 @@ BLS_HD g2_proj g2_to_proj(const g2_jac& q) {
 // T <- 2T, returns the tangent line at T evaluated at P, times 2 Y Z^2 (an Fp2 factor):
 //   (Y^2 - 3b' Z^2)  -  3 X^2 * xp v  +  2 Y Z * yp vw          with b' = 4 xi
 //   X3 = 2 X Y (B - 3E), Y3 = (B + 3E)^2 - 12 E^2, Z3 = 4 B H;  B = Y^2, C = Z^2, E = 3 b' C, H = 2 Y Z
-BLS_MID line_t miller_dbl_step(g2_proj& t, const g1_pre& p) {
-    fp2 B = fp2_sqr(t.y);
-    fp2 C = fp2_sqr(t.z);
-    fp2 X2 = fp2_sqr(t.x);
+template <class M>
+BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
+    fp2 B = m.sqr(t.y);
+    fp2 C = m.sqr(t.z);
+    fp2 X2 = m.sqr(t.x);
     fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));                       // 4 xi C   (2 -> 4 units, carry, 2)
     fp2 E = fp2_reduce(fp2_add_nc(fp2_dbl_nc(C4), C4));                                 // 12 xi C = 3 b' C   (6 units)
     fp2 F = fp2_add_nc(fp2_dbl_nc(E), E);                                                // 3E, 3 units
-    fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_sqr(fp2_add(t.y, t.z)), B), C));         // 2 Y Z
-    fp2 E2 = fp2_sqr(E);
+    fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.y, t.z)), B), C));           // 2 Y Z
+    fp2 E2 = m.sqr(E);
     fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
-    fp2 S = fp2_sqr(fp2_carry(fp2_add_nc(B, F)));
-    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(fp2_sqr(fp2_add(t.x, t.y)), X2), B));     // 2 X Y = (X + Y)^2 - X^2 - Y^2: a squaring for a product
-    fp2 x3 = fp2_mul(XY2, fp2_carry(fp2_sub_nc(B, F)));
+    fp2 S = m.sqr(fp2_carry(fp2_add_nc(B, F)));
+    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.x, t.y)), X2), B));       // 2 X Y = (X + Y)^2 - X^2 - Y^2: a squaring for a product
+    fp2 x3 = m.mul(XY2, fp2_carry(fp2_sub_nc(B, F)));
     fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));             // S - 12 E^2
-    fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(fp2_mul(B, H))));
+    fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(m.mul(B, H))));
     t = g2_proj{x3, y3, z3};
-    return line_t{fp2_mul_fp(fp2_sub_nc(B, E), p.z3), fp2_mul_fp(X2, p.nxz3), fp2_mul_fp(H, p.y)};
+    fp2 BE = fp2_sub_nc(B, E);
+    return line_t{fp2{m.mul(BE.c0, p.z3), m.mul(BE.c1, p.z3)}, fp2{m.mul(X2.c0, p.nxz3), m.mul(X2.c1, p.nxz3)}, fp2{m.mul(H.c0, p.y), m.mul(H.c1, p.y)}};
 }
+BLS_MID line_t miller_dbl_step(g2_proj& t, const g1_pre& p) { return miller_dbl_step_m(t, p, mul_shared{}); }
 
 // The same step with a team of lanes per pair (see jac_dbl_team, curve.hpp): five squarings, then two, then two products, then the
 // six Fp products of the line scaling, each group as one multiplier call.  Formula, carries and reductions are miller_dbl_step's.
@@ -158,6 +161,9 @@ BLS_MID line_t miller_add_step_team(g2_proj& t, const g2_proj& q, const g1_pre& 
 
 // Emits the 68 lines of pair (P, Q) through sink(step, line).  A pair with P or Q at infinity
 // contributes 1 (blst skips such pairs in the Miller loop).
+#ifndef BLS_LINES_MUL
+#define BLS_LINES_MUL mul_shared           // A/B switch: who multiplies in the 63 doubling steps of miller_lines
+#endif
 template <class Sink>
 BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
     bool skip = jac_is_inf(pj) | jac_is_inf(qj);
@@ -167,7 +173,7 @@ BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
     g2_proj t = q;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
-        line_t l = miller_dbl_step(t, p);
+        line_t l = miller_dbl_step_m(t, p, BLS_LINES_MUL{});
         sink(s++, skip ? line_one() : l);
         if ((k::X_ABS >> bit) & 1) {
             line_t a = miller_add_step(t, q, p);

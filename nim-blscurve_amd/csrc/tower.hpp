@@ -129,7 +129,7 @@ struct line_ops_regs {
     BLS_HD fp2 mul_l0l1(const fp2& x) const { return fp2_mul(x, fp2_add_nc(l.l0, l.l1)); }
     BLS_HD fp2 mul_l0m1(const fp2& x) const { return fp2_mul(x, fp2_carry(fp2_add_nc(l.l0, m1))); }
 };
-BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) {
+BLS_MID fp12 fp12_mul_by_line_karatsuba(const fp12& f, const line_t& l) {
     return fp12_mul_by_line_ops(f, line_ops_regs{l, fp2_add_nc(l.l1, l.l2)});
 }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -143,6 +143,17 @@ struct line_ops_lds {
         fp2_lds_put(base + 2 * BLS_LDS_SLOT, l.l2);
         fp2_lds_put(base + 3 * BLS_LDS_SLOT, fp2_add_nc(l.l1, l.l2));
     }
+#if defined(BLS_LINEPROD_INL)
+    // multiplier bodies expanded in place, the line coefficient read from its LDS slot where it is used (no call, no hand-over slot)
+    __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base)); }
+    __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + BLS_LDS_SLOT)); }
+    __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + 2 * BLS_LDS_SLOT)); }
+    __device__ __forceinline__ fp2 mul_m1(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + 3 * BLS_LDS_SLOT)); }
+    __device__ __forceinline__ fp2 mul_l0l1(const fp2& x) const { return fp2_mul_inl(x, fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT))); }
+    __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const {
+        return fp2_mul_inl(x, fp2_carry(fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + 3 * BLS_LDS_SLOT))));
+    }
+#else
     __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_lds(x, base); }
     __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_lds(x, base + BLS_LDS_SLOT); }
     __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_lds(x, base + 2 * BLS_LDS_SLOT); }
@@ -151,12 +162,50 @@ struct line_ops_lds {
     __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const {
         return fp2_mul(x, fp2_carry(fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + 3 * BLS_LDS_SLOT))));
     }
+#endif
 };
 #else
 // host pass of a .hip translation unit: kernels are parsed, never run
 struct line_ops_lds : line_ops_regs {
     void park(const line_t&) const {}
 };
+#endif
+// f * line as a SCHOOLBOOK product with one reduction per output coefficient (fp_dotn_core): with f = (a0 + a1 v + a2 v^2) +
+// (b0 + b1 v + b2 v^2) w and the line l0 + l1 v + l2 v w (v^3 = xi, w^2 = v)
+//   c0.a0 = a0 l0 + xi a2 l1 + xi b1 l2      c1.a0 = b0 l0 + xi b2 l1 + xi a2 l2
+//   c0.a1 = a1 l0 +    a0 l1 + xi b2 l2      c1.a1 = b1 l0 +    b0 l1 +    a0 l2
+//   c0.a2 = a2 l0 +    a1 l1 +    b0 l2      c1.a2 = b2 l0 +    b1 l1 +    a1 l2
+// every coefficient an Fp2 sum of three products = two Fp dot products of six terms: 12 x (6 x 196 + 196) = 16 464 multiply-adds and 12
+// reductions where the Karatsuba form (fp12_mul_by_line_ops) takes 15 288 and 26 reductions plus ~1 500 instructions of operand sums,
+// differences and carry steps: ~17 600 instructions per line instead of ~21 000.  The xi multiples are limb-wise (real part a
+// difference of canonical limbs: 1 unit; imaginary part a sum: 2 units), so the column bound of fp_dotn holds with exactly 8 units.
+// Inputs: f with canonical limbs and |v| < 2p per coefficient (what this function returns; fp12_from_line of a stored line), line
+// coefficients as k_lines stores them (|v| < 2p, limbs within one unit).  Output: canonical limbs, |v| < 2p: stable under iteration,
+// and already below the bound fp12_mul wants, so no fp12_reduce is needed behind it.
+BLS_HD fp2 fp2_dot3(const fp2& X, const fp2& Y, const fp2& Z, const fp2& L0, const fp2& L1, const fp2& L2) {
+    const fp y[6] = {L0.c0, L0.c1, L1.c0, L1.c1, L2.c0, L2.c1};
+    const fp xr[6] = {X.c0, fp_neg(X.c1), Y.c0, fp_neg(Y.c1), Z.c0, fp_neg(Z.c1)};
+    const fp xi[6] = {X.c1, X.c0, Y.c1, Y.c0, Z.c1, Z.c0};
+    return fp2{fp_dotn<6>(xr, y), fp_dotn<6>(xi, y)};
+}
+// xi * a for a with canonical limbs: (a0 - a1, a0 + a1), no carry step
+BLS_HD fp2 fp2_mul_xi_pos(const fp2& a) { return fp2{fp_sub_pos(a.c0, a.c1), fp_add_nc(a.c0, a.c1)}; }
+BLS_MID fp12 fp12_mul_by_line_lazy(const fp12& f, const line_t& l) {
+    const fp6 &a = f.c0, &b = f.c1;
+    const fp2 xa2 = fp2_mul_xi_pos(a.a2), xb1 = fp2_mul_xi_pos(b.a1), xb2 = fp2_mul_xi_pos(b.a2);
+    fp12 r;
+    r.c0.a0 = fp2_dot3(a.a0, xa2, xb1, l.l0, l.l1, l.l2);
+    r.c0.a1 = fp2_dot3(a.a1, a.a0, xb2, l.l0, l.l1, l.l2);
+    r.c0.a2 = fp2_dot3(a.a2, a.a1, b.a0, l.l0, l.l1, l.l2);
+    r.c1.a0 = fp2_dot3(b.a0, xb2, xa2, l.l0, l.l1, l.l2);
+    r.c1.a1 = fp2_dot3(b.a1, b.a0, a.a0, l.l0, l.l1, l.l2);
+    r.c1.a2 = fp2_dot3(b.a2, b.a1, a.a1, l.l0, l.l1, l.l2);
+    return r;
+}
+#if defined(BLS_LINEPROD_KARATSUBA)
+BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) { return fp12_mul_by_line_karatsuba(f, l); }
+#else
+BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) { return fp12_mul_by_line_lazy(f, l); }
 #endif
 BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
 

@@ -66,6 +66,20 @@ int main(int argc, char** argv) {
         for (unsigned i = 0; i < n; i++) upd &= mi355_bls_aggv_update(tiny, sets + 320 * (size_t)i, sets + 320 * (size_t)i + 96, 32);
         printf("batch%d aggv_updates %d\n", k, upd);
         printf("batch%d aggv_finish %d\n", k, mi355_bls_aggv_finish(tiny, sets + 128));
+        {   /* aggregateAll on the batch's signatures (core :179-195,211) -> AggregateSignature (blst_p2, 288 B) -> finish(AggregateSignature) (core :357) */
+            unsigned char* sg = (unsigned char*)malloc(192 * (size_t)n);
+            unsigned char agg[288];
+            for (unsigned i = 0; i < n; i++) memcpy(sg + 192 * (size_t)i, sets + 320 * (size_t)i + 128, 192);
+            printf("batch%d g2_aggregate %d\n", k, mi355_bls_g2_aggregate(tiny, sg, n, agg));
+            mi355_bls_aggv_init(tiny);
+            for (unsigned i = 0; i < n; i++) mi355_bls_aggv_update(tiny, sets + 320 * (size_t)i, sets + 320 * (size_t)i + 96, 32);
+            printf("batch%d aggv_p2_finish %d\n", k, mi355_bls_aggv_finish_p2(tiny, agg));
+            mi355_bls_g2_aggregate(tiny, sg, n - 1, agg);                       /* one signature short: not the aggregate */
+            mi355_bls_aggv_init(tiny);
+            for (unsigned i = 0; i < n; i++) mi355_bls_aggv_update(tiny, sets + 320 * (size_t)i, sets + 320 * (size_t)i + 96, 32);
+            printf("batch%d aggv_p2_short %d\n", k, mi355_bls_aggv_finish_p2(tiny, agg));
+            free(sg);
+        }
         unsigned char zero_pk[96] = {0};
         mi355_bls_aggv_init(tiny);
         printf("batch%d aggv_inf_update %d\n", k, mi355_bls_aggv_update(tiny, zero_pk, sets + 96, 32));

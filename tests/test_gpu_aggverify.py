@@ -125,3 +125,45 @@ def test_streaming_context(m):
     assert m.aggregateVerify(tiny, pkb, [b"x"] + texts[1:], sig) is False
     tiny.close()
     cache.close()
+
+
+def test_aggregate_all_signatures_and_aggregate_signature_overloads(m):
+    """aggregateAll on signatures (core :179-195,211) and finish(signature: AggregateSignature) (core :357): the 288-byte Jacobian
+    aggregate the device builds equals the oracle's sum, and aggregateVerify / ContextCoreAggregateVerify.finish accept it."""
+    import bench
+    import c_oracle as co
+    cache = m.BatchedBLSVerifierCache.init(max_sets=256, numThreads=4)
+    c, pks, msgs, sigs = _case("n9")
+    rec = bytes.fromhex(c["sets"])
+    sig_bytes = [rec[320 * i + 128:320 * i + 320] for i in range(c["n"])]
+    agg288 = m.aggregateAllSignatures(cache, sig_bytes)
+    assert len(agg288) == 288
+    want = o.g2_to_blst_affine(o.aggregate_g2(sigs))
+    assert bench.g2_jacobian_image_to_affine(agg288) == want
+    assert m.aggregateAllSignatures(cache, []) is None
+    # an infinity signature in the list contributes nothing; a single signature is itself
+    assert bench.g2_jacobian_image_to_affine(m.aggregateAllSignatures(cache, sig_bytes[:4] + [bytes(192)] + sig_bytes[4:])) == want
+    assert bench.g2_jacobian_image_to_affine(m.aggregateAllSignatures(cache, sig_bytes[:1])) == sig_bytes[0]
+    # the AggregateSignature overloads
+    assert m.aggregateVerify(cache, pks, msgs, agg288) is True
+    assert m.aggregateVerify(cache, pks, msgs[1:] + msgs[:1], agg288) is False
+    ctx = m.ContextCoreAggregateVerify(cache)
+    ctx.init()
+    for p, x in zip(pks, msgs):
+        assert ctx.update(p, x) is True
+    assert ctx.finish(agg288) is True
+    ctx.init()
+    for p, x in zip(pks, msgs[1:] + msgs[:1]):
+        ctx.update(p, x)
+    assert ctx.finish(agg288) is False
+    # more signatures than one wave round, against the C restatement's sum
+    pks2, msgs2, agg_aff = _agg_inputs(m, 3000, 7_700_000)
+    import torch
+    gen = m.BatchedBLSVerifierCache.init(max_sets=3000)
+    rec2 = bytes(bench.sign_records(m, gen, torch.device("cuda", 0), range(7_700_000, 7_703_000)).cpu().numpy())
+    gen.close()
+    a2 = m.aggregateAllSignatures(cache, [rec2[320 * i + 128:320 * i + 320] for i in range(3000)])
+    assert bench.g2_jacobian_image_to_affine(a2) == agg_aff
+    big = m.BatchedBLSVerifierCache.init(max_sets=4096, numThreads=4)
+    assert m.aggregateVerify(big, pks2, msgs2, a2) is True
+    assert co.aggregate_verify(pks2, msgs2, agg_aff) is True

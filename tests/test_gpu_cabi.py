@@ -38,6 +38,10 @@ def test_plain_c_caller(tmp_path):
     # streaming aggregateVerify: every update accepted, a non-aggregate signature rejected; infinity key -> update and finish false
     for k in ("batch0", "batch1"):
         assert (kv[k + " aggv_updates"], kv[k + " aggv_finish"], kv[k + " aggv_inf_update"], kv[k + " aggv_inf_finish"]) == ("1", "0", "0", "0")
+    # aggregateAll on signatures + finish(AggregateSignature): the naive aggregate check passes for BOTH batches (the forged pair of
+    # t_batch_verifier.nim:198-244 is built to pass it), an aggregate that misses one signature fails
+    for k in ("batch0", "batch1"):
+        assert (kv[k + " g2_aggregate"], kv[k + " aggv_p2_finish"], kv[k + " aggv_p2_short"]) == ("0", "1", "0")
     want = [v for v in golden("msm")["msm"] if v["n"] == 32][0]["result_affine"]
     for k in ("msm_contiguous", "msm_pointer_list", "msm_ctx", "msm_multi", "msm_partials_added"):
         assert o.g1_to_blst_affine(g1_jac_to_affine(bytes.fromhex(kv[k]))).hex() == want, k

@@ -82,3 +82,31 @@ def test_sixteen_batches_of_4096(m):
     bad[320 * j + 128:320 * j + 320] = d[320 * i + 128:320 * i + 320]
     assert m.batchVerifyMany_device(cache, bad.data_ptr(), [n] * k, rnds) == [b != 9 for b in range(k)]
     cache.close()
+
+
+def test_same_rnd_in_two_batches_cannot_cancel_across_them(m):
+    """Two batches with the SAME secureRandomBytes and the same count have identical blinding scalars at identical indices, so a
+    forger can make errors cancel ACROSS them: sig_A[i] + D in one, sig_B[i] - D in the other.  The product of the two batch checks
+    is then one although both batches are invalid; k separate batchVerify calls reject both.  The library must notice the equal
+    rnds, skip the merged pass and return the verdicts of separate calls."""
+    import bls12381_py as o
+    import c_oracle as co
+    n, nt, i = 8, 4, 5
+    a = bytearray(co.make_batch(n, seed=4100))
+    b = bytearray(co.make_batch(n, seed=4200))
+    d = o.g2_from_blst_affine(bytes(a[320 * 2 + 128:320 * 2 + 320]))                     # any G2 point
+    sa = o.g2_from_blst_affine(bytes(a[320 * i + 128:320 * i + 320]))
+    sb = o.g2_from_blst_affine(bytes(b[320 * i + 128:320 * i + 320]))
+    a[320 * i + 128:320 * i + 320] = o.g2_to_blst_affine(o.g2_add(sa, d))
+    b[320 * i + 128:320 * i + 320] = o.g2_to_blst_affine(o.g2_add(sb, o.g2_neg(d)))
+    a, b = bytes(a), bytes(b)
+    rnd = _rnd(77)
+    cache = m.BatchedBLSVerifierCache.init(max_sets=256, numThreads=nt)
+    assert co.batch_verify(a, rnd, nt) is False and co.batch_verify(b, rnd, nt) is False
+    assert m.batchVerify(cache, a, rnd) is False and m.batchVerify(cache, b, rnd) is False
+    assert m.batchVerifyMany(cache, [a, b], [rnd, rnd]) == [False, False]                 # equal rnds: verified one by one
+    # with independent rnds the merged pass runs and rejects too (the scalars at index i differ, nothing cancels)
+    assert m.batchVerifyMany(cache, [a, b], [rnd, _rnd(78)]) == [False, False]
+    # equal rnds on VALID batches: still correct, just not merged
+    va, vb = co.make_batch(n, seed=4100), co.make_batch(n, seed=4200)
+    assert m.batchVerifyMany(cache, [va, vb, b""], [rnd, rnd, rnd]) == [True, True, False]

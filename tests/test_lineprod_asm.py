@@ -1,0 +1,26 @@
+"""The generator of k_lineprod's hand-allocated assembly loop (nim-blscurve_amd/tools/gen_lineprod_asm.py): its own one-lane interpreter
+executes the generated instruction list and checks f * line against big-integer arithmetic (no GPU).  The GPU parity tests
+(test_gpu_batch / test_gpu_headline: GT values against the C oracle) cover the assembled loop itself."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "nim-blscurve_amd", "tools", "gen_lineprod_asm.py")
+
+
+def test_generated_line_product_matches_bigint_model():
+    r = subprocess.run([sys.executable, GEN, "--selftest"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "selftest ok" in r.stdout
+    assert "16464 multiply-adds" in r.stdout          # 12 dot products of six terms: the census bench.MAD_PER_TUPLE["k_lineprod"] / 68 lines
+
+
+def test_emitted_text_is_one_statement_with_clobbers():
+    r = subprocess.run([sys.executable, GEN], capture_output=True, text=True)
+    assert r.returncode == 0
+    t = r.stdout
+    assert "#define BLS_LINEPROD_ASM_BODY" in t and "#define BLS_LINEPROD_ASM_CLOBBERS" in t
+    assert t.count("v_mad_i64_i32") == 16464                      # one unrolled line product (line 0 only initialises f)
+    assert "scratch_" not in t and "s_swappc" not in t            # no spills, no calls
+    assert '"a255"' in t and '"v249"' in t and '"v250"' not in t  # v250.. stay the compiler's
