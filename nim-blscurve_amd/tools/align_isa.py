@@ -203,6 +203,12 @@ def main():
         i += 1
     lines = keep
 
+    # (Round 4 tried to shrink the callee-entry wait of the shared multiplier bodies - `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)`, which every
+    # non-kernel function opens with - to lgkmcnt(0): they touch no vector memory.  UNSAFE: hipcc's callers rely on that wait.  They load
+    # straight into the argument registers and call without waiting (fp_pow_sched: scratch_load_dwordx4 v[14:17] ... s_swappc_b64), so
+    # the callee read stale arguments and k_hash_map never ended.  Not done.)
+    relaxed = 0
+
     # 1. _e32 -> _e64 wherever the assembler takes it
     conv = {}
     for i, l in enumerate(lines):
@@ -289,8 +295,8 @@ def main():
     after = verify(a.objdump, o1)
     check_model(a.objdump, o1, out)
     worst = sorted(after[2].items(), key=lambda kv: -kv[1])[:5]
-    print("align_isa: %d of %d 8-byte instructions misaligned before, %d of %d after; %d _e32 re-encoded, %d s_nop inserted, %d asm wait states removed; worst: %s"
-          % (before[1], before[0], after[1], after[0], len(conv), nops, stripped, worst))
+    print("align_isa: %d of %d 8-byte instructions misaligned before, %d of %d after; %d _e32 re-encoded, %d s_nop inserted, %d asm wait states removed, %d callee-entry waits relaxed; worst: %s"
+          % (before[1], before[0], after[1], after[0], len(conv), nops, stripped, relaxed, worst))
 
 
 if __name__ == "__main__":

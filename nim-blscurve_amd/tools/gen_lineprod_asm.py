@@ -10,13 +10,16 @@ Why assembly: at one wave per SIMD (an Fp12 accumulator is 168 registers) nothin
 this loop stalls a lot - register spills reloaded right in front of their use (each a full memory latency), the next line's loads
 waited for where they are issued, 56 argument moves and two instruction-fetch bubbles (~70 cycles each, tools/ubench_dep.hip) per
 out-of-line multiplier call: 11-20 % of the wave's cycles are waits (profiles/r04_ab).  Here every value has a fixed home:
-  v0..v95     the line's three Fp2 coefficients as they lie in memory (16 words per Fp, 14 limbs + 2 pad)
-  v96..v137   the negated imaginary parts of the line (the real part of an Fp2 product subtracts im * im)
-  v138..v221  three Fp2 operand slots, copied from the accumulator for the coefficient being computed
-  v222..v235  the 14 Montgomery quotient digits m_k; v[236:237] the column accumulator; v238.. temporaries and addresses
+  v0..v83     the line's three Fp2 coefficients (14 limbs per Fp)
+  v84..v125   the negated imaginary parts of the line (the real part of an Fp2 product subtracts im * im)
+  v126..v209  three Fp2 operand slots, copied from the accumulator for the coefficient being computed
+  v210..v223  the 14 Montgomery quotient digits m_k; v[224:225] the column accumulator; v226..v239 the real part of the coefficient
+              being computed (its imaginary part lands in the first operand slot, whose limbs are dead by then); v240.. addresses
   a0..a251    nine blocks of 28: the six Fp2 coefficients of f and three blocks that take new coefficients while old ones are read
   SGPRs       the limbs of p, -1/p mod 2^28, the limb mask, the loop state
-no scratch, no LDS, no calls, one backward jump per line.
+no scratch, no spills.  The two dot products of one coefficient (2 880 instructions, 23 KB) are ONE subroutine called six times per
+line with its operands in place: the hot code is 33 KB.  (Fully unrolled, a line was 146 KB of straight code, and a loop body that
+does not fit the 64 KB instruction cache costs ~4.6 cycles per instruction instead of ~4.1-4.3: tools/ubench_icache.hip.)
 
 Output: csrc-includable text, one C string literal per instruction (build.sh writes it to build/lineprod_asm.inc).
 `--selftest` executes the generated instruction list for one lane in a small interpreter and checks f * line against big-integer
@@ -37,21 +40,21 @@ PL = [(P >> (LB * i)) & MASK for i in range(NL)]
 ONE = [((R % P) >> (LB * i)) & MASK for i in range(NL)]
 
 # ---- register plan -------------------------------------------------------------------------------------------------------------
-L_BASE, NL_BASE, X_BASE, M_BASE, ACC, TMP = 0, 96, 138, 222, 236, 238
+L_BASE, NL_BASE, X_BASE, M_BASE, ACC, R_BASE, TMP = 0, 84, 126, 210, 224, 226, 240
 V_OFF, V_OFF2, V_IDX, V_T = 242, 243, 244, 245          # line offset (bytes), output offset, pair index of this lane, scratch
 V_AD, V_LDS = 246, 248                                  # 64-bit address of the LDS-DMA loads (pair), this lane's byte address in the DMA buffer
 NBLK = 9
 S_P, S_N0, S_MASK = 40, 54, 55                         # s40..s53 limbs of p
 S_CNT, S_PC, S_T = 56, 58, 60                          # loop counter, saved loop-top pc (pair), scalar temporaries (s60..s63)
 S_BASE, S_STR, S_NEXT = 64, 66, 68                     # step base (pair), plane stride in bytes as a 64-bit pair, exec mask of the NEXT line (pair)
-S_LAST = 70
+S_LAST, S_SUB, S_RET = 70, 72, 74                      # lines left; address of the coefficient subroutine (pair); its return address (pair)
 CLOBBER_V = 250                                        # v0..v249 are ours
 # coefficient order inside f: a0 a1 a2 b0 b1 b2 (tower slots c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2)
 A0, A1, A2, B0, B1, B2 = range(6)
 
 
 def lreg(c, part, i):
-    return L_BASE + 32 * c + 16 * part + i
+    return L_BASE + 28 * c + 14 * part + i
 
 
 def nlreg(c, i):
@@ -69,7 +72,8 @@ class Gen:
     def e(self, *t):
         self.ins.append(t)
 
-    # -- one Montgomery dot product of the pairs [(xv, yv)] (lists of 14 VGPR numbers each) -> result limbs to the AGPRs dst[0..13]
+    # -- one Montgomery dot product of the pairs [(xv, yv)] (lists of 14 VGPR numbers each) -> result limbs to the VGPRs dst[0..13]
+    #    (dst[k] may be a register that is dead from column 14 + k on: an m_k, or limb k of an operand whose pairs come first)
     def dot(self, pairs, dst):
         first = True
         for kk in range(2 * NL - 1):
@@ -87,10 +91,23 @@ class Gen:
             else:
                 for i in range(kk - NL + 1, NL):
                     self.e("mad", M_BASE + i, ("s", S_P + kk - i), False)
-                self.e("and", TMP, S_MASK, ACC)
-                self.e("awrite", dst[kk - NL], TMP)
+                self.e("and", dst[kk - NL], S_MASK, ACC)
             self.e("ashr28")
-        self.e("awrite", dst[NL - 1], ACC)
+        self.e("mov", dst[NL - 1], ACC)
+
+    def coefficient_body(self):
+        """the subroutine: (X, Y, Z) in the operand slots times (l0, l1, l2): real part -> v[R_BASE..], imaginary part -> slot 0's real limbs"""
+        re_pairs, im_pairs = [], []
+        for s_ in range(3):
+            xr = [xreg(s_, 0, i) for i in range(NL)]
+            xi_ = [xreg(s_, 1, i) for i in range(NL)]
+            lr = [lreg(s_, 0, i) for i in range(NL)]
+            li = [lreg(s_, 1, i) for i in range(NL)]
+            nli = [nlreg(s_, i) for i in range(NL)]
+            re_pairs += [(xr, lr), (xi_, nli)]
+            im_pairs += [(xr, li), (xi_, lr)]
+        self.dot(re_pairs, [R_BASE + i for i in range(NL)])
+        self.dot(im_pairs, [xreg(0, 0, i) for i in range(NL)])
 
     def load_slot(self, slot, blk, xi):
         """operand slot <- coefficient in AGPR block blk (xi: times 1 + u, limb-wise: (re - im, re + im))"""
@@ -106,19 +123,13 @@ class Gen:
 
     def output(self, target_blk, ops):
         """new coefficient = sum over slot s of ops[s] * l_s; ops[s] = (block, xi)"""
-        for s, (blk, xi) in enumerate(ops):
-            self.load_slot(s, blk, xi)
-        re_pairs, im_pairs = [], []
-        for s in range(3):
-            xr = [xreg(s, 0, i) for i in range(NL)]
-            xi_ = [xreg(s, 1, i) for i in range(NL)]
-            lr = [lreg(s, 0, i) for i in range(NL)]
-            li = [lreg(s, 1, i) for i in range(NL)]
-            nli = [nlreg(s, i) for i in range(NL)]
-            re_pairs += [(xr, lr), (xi_, nli)]
-            im_pairs += [(xr, li), (xi_, lr)]
-        self.dot(re_pairs, [28 * target_blk + i for i in range(NL)])
-        self.dot(im_pairs, [28 * target_blk + 14 + i for i in range(NL)])
+        for s_, (blk, xi) in enumerate(ops):
+            self.load_slot(s_, blk, xi)
+        self.e("call")
+        for i in range(NL):
+            self.e("awrite", 28 * target_blk + i, R_BASE + i)
+        for i in range(NL):
+            self.e("awrite", 28 * target_blk + 14 + i, xreg(0, 0, i))
 
     def neg_line_im(self):
         for c in range(3):
@@ -188,6 +199,10 @@ def text_of(t):
         return "v_sub_u32_e64 v%d, 0, v%d" % (t[1], t[2])
     if op == "movi":
         return "v_mov_b32_e32 v%d, 0x%x" % (t[1], t[2])
+    if op == "mov":
+        return "v_mov_b32_e32 v%d, v%d" % (t[1], t[2])
+    if op == "call":
+        return "s_swappc_b64 s[%d:%d], s[%d:%d]" % (S_RET, S_RET + 1, S_SUB, S_SUB + 1)
     if op == "raw":
         return t[1]
     raise ValueError(op)
@@ -211,10 +226,16 @@ def dma_issue_text():
 
 
 def lds_fetch_text():
-    """the line that the last dma_issue_text brought in: LDS -> v0..v95 (its memory image: 16 words per Fp)"""
+    """the line that the last dma_issue_text brought in: LDS (its memory image, 16 words per Fp) -> v0..v83 (14 limbs per Fp)"""
     out = ["s_waitcnt vmcnt(0)"]
-    for k in range(24):
-        out.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (L_BASE + 4 * k, L_BASE + 4 * k + 3, V_LDS, 1024 * k))
+    for c in range(3):
+        for part in range(2):
+            k = 4 * (2 * c + part)
+            for q in range(3):
+                r = lreg(c, part, 4 * q)
+                out.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (r, r + 3, V_LDS, 1024 * (k + q)))
+            r = lreg(c, part, 12)
+            out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (r, r + 1, V_LDS, 1024 * (k + 3)))
     out.append("s_waitcnt lgkmcnt(0)")
     return out
 
@@ -237,6 +258,16 @@ def kernel_text():
     T += ["v_lshlrev_b32_e64 v%d, 4, v%d" % (V_LDS, V_T), "v_add_u32_e64 v%d, %%6, v%d" % (V_LDS, V_LDS)]
     T += ["v_add_u32_e64 v%d, %%3, v%d" % (V_IDX, V_T), "v_lshlrev_b32_e64 v%d, 4, v%d" % (V_OFF, V_IDX)]
     g = Gen(); g.init_one(); T += [text_of(t) for t in g.ins]
+    # the coefficient subroutine sits in front of the loop that calls it; s[S_SUB] = its address
+    T += ["s_getpc_b64 s[%d:%d]" % (S_SUB, S_SUB + 1), ".Llp_sp%=:",
+          "s_add_u32 s%d, s%d, (.Llp_sub%%=-.Llp_sp%%=)&4294967295" % (S_SUB, S_SUB),
+          "s_addc_u32 s%d, s%d, (.Llp_sub%%=-.Llp_sp%%=)>>32" % (S_SUB + 1, S_SUB + 1),
+          "s_getpc_b64 s[%d:%d]" % (S_T + 2, S_T + 3), ".Llp_mp%=:",
+          "s_add_u32 s%d, s%d, (.Llp_main%%=-.Llp_mp%%=)&4294967295" % (S_T + 2, S_T + 2),
+          "s_addc_u32 s%d, s%d, (.Llp_main%%=-.Llp_mp%%=)>>32" % (S_T + 3, S_T + 3),
+          "s_setpc_b64 s[%d:%d]" % (S_T + 2, S_T + 3), ".Llp_sub%=:"]
+    g = Gen(); g.coefficient_body(); T += [text_of(t) for t in g.ins]
+    T += ["s_setpc_b64 s[%d:%d]" % (S_RET, S_RET + 1), ".Llp_main%=:"]
     # line 0: bring it in (the "next line" of a position one line before the first), then f <- line 0 under exec = (pair index < npairs)
     T += ["v_subrev_u32_e32 v%d, 64, v%d" % (V_IDX, V_IDX), "v_subrev_u32_e32 v%d, 0x400, v%d" % (V_OFF, V_OFF), "s_mov_b32 s%d, %%4" % S_LAST]
     T += next_mask_text() + dma_issue_text()
@@ -248,13 +279,8 @@ def kernel_text():
     g = Gen(); g.from_line(); T += [text_of(t) for t in g.ins]
     T += ["s_mov_b64 exec, -1"]
     # lines 1 .. rounds - 1
-    T += ["s_cmp_lt_i32 s%d, 1" % S_CNT, "s_cbranch_scc0 .Llp_enter%="]
-    # far jump over the loop body (a conditional branch reaches +-128 KB only)
-    T += ["s_getpc_b64 s[%d:%d]" % (S_T + 2, S_T + 3), ".Llp_post%=:",
-          "s_add_u32 s%d, s%d, (.Llp_end%%=-.Llp_post%%=)&4294967295" % (S_T + 2, S_T + 2),
-          "s_addc_u32 s%d, s%d, (.Llp_end%%=-.Llp_post%%=)>>32" % (S_T + 3, S_T + 3),
-          "s_setpc_b64 s[%d:%d]" % (S_T + 2, S_T + 3)]
-    T += [".Llp_enter%=:", "s_getpc_b64 s[%d:%d]" % (S_PC, S_PC + 1)]                                                 # = address of the next instruction
+    T += ["s_cmp_lt_i32 s%d, 1" % S_CNT, "s_cbranch_scc1 .Llp_end%="]
+    T += ["s_getpc_b64 s[%d:%d]" % (S_PC, S_PC + 1)]                                                 # = address of the next instruction
     T += ["v_add_u32_e64 v%d, 64, v%d" % (V_IDX, V_IDX), "v_add_u32_e32 v%d, 0x400, v%d" % (V_OFF, V_OFF)]
     T += ["s_sub_u32 s%d, s%d, 1" % (S_LAST, S_CNT)]                                                                  # lines left behind this one
     T += ["v_cmp_gt_u32_e64 vcc, %%2, v%d" % V_IDX, "s_and_saveexec_b64 s[%d:%d], vcc" % (S_T, S_T + 1)]
@@ -274,7 +300,7 @@ def kernel_text():
 
 
 def clobbers():
-    c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(S_P, S_LAST + 1)] + ["vcc", "memory"]
+    c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(S_P, S_RET + 2)] + ["vcc", "memory"]
     return ", ".join('"%s"' % x for x in c)
 
 
@@ -286,7 +312,11 @@ def s32(x):
 
 def run(ins, v, a, s):
     acc = 0
+    sub = Gen(); sub.coefficient_body()
+    flat = []
     for t in ins:
+        flat += sub.ins if t[0] == "call" else [t]
+    for t in flat:
         op = t[0]
         if op == "mad":
             _, x, (kind, y), first = t
@@ -315,6 +345,8 @@ def run(ins, v, a, s):
             v[t[1]] = (-v[t[2]]) & 0xffffffff
         elif op == "movi":
             v[t[1]] = t[2]
+        elif op == "mov":
+            v[t[1]] = v[t[2]]
         else:
             raise ValueError(op)
 
@@ -371,9 +403,12 @@ def selftest(rounds=3):
     assert value_of([a[i] for i in range(NL)]) == R % P and all(x == 0 for x in a[NL:168])
     g = Gen(); g.from_line(); run(g.ins, v, a, s)
     assert [a[28 * A1 + i] for i in range(NL)] == [v[lreg(1, 0, i)] for i in range(NL)] and all(a[28 * B0 + i] == 0 for i in range(28))
-    n = len(Gen().__class__ and (lambda gg: (gg.product(), gg.ins)[1])(Gen()))
-    mads = sum(1 for t in (lambda gg: (gg.product(), gg.ins)[1])(Gen()) if t[0] == "mad")
-    print("gen_lineprod_asm selftest ok: %d instructions per line, %d multiply-adds (%.1f %%)" % (n, mads, 100.0 * mads / n))
+    g = Gen(); g.product()
+    sub = Gen(); sub.coefficient_body()
+    n = len(g.ins) + 6 * (len(sub.ins) + 1)
+    mads = 6 * sum(1 for t in sub.ins if t[0] == "mad")
+    print("gen_lineprod_asm selftest ok: %d instructions per line (%d in the caller, %d in the subroutine), %d multiply-adds (%.1f %%)"
+          % (n, len(g.ins), len(sub.ins), mads, 100.0 * mads / n))
 
 
 def main():

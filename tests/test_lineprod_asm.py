@@ -21,6 +21,7 @@ def test_emitted_text_is_one_statement_with_clobbers():
     assert r.returncode == 0
     t = r.stdout
     assert "#define BLS_LINEPROD_ASM_BODY" in t and "#define BLS_LINEPROD_ASM_CLOBBERS" in t
-    assert t.count("v_mad_i64_i32") == 16464                      # one unrolled line product (line 0 only initialises f)
-    assert "scratch_" not in t and "s_swappc" not in t            # no spills, no calls
+    assert t.count("v_mad_i64_i32") == 2744                       # ONE copy of the coefficient subroutine: two dot products of 6 x 196 + 196
+    assert t.count("s_swappc_b64") == 6                           # called once per coefficient of the line product
+    assert "scratch_" not in t                                    # no spills
     assert '"a255"' in t and '"v249"' in t and '"v250"' not in t  # v250.. stay the compiler's
