@@ -318,13 +318,13 @@ class ShardedRun:
         return float(tmax.item())
 
 
-def msm_rows_sharded(m, cache, dev, rank, world, backend, ctl):
+def msm_rows_sharded(m, cache, dev, rank, world, backend, ctl, log2_points=20):
     """G1 MSM points/s on N GPUs (BASELINE.json's second metric), point-sharded: every rank computes the
     full-width partial of its points and leaves it in device memory, ONE all_gather of 144 bytes per rank, rank 0 adds the
     partials.  weak: 2^20 points per GPU (the config-4 shape per device); strong: 2^20 points in all."""
     import numpy as np
     out = {}
-    nm = 1 << 20
+    nm = 1 << log2_points
     msg = hashlib.sha256(b"Mr F was here").digest()
     import random
     rng = random.Random(7 + rank)
@@ -348,7 +348,7 @@ def msm_rows_sharded(m, cache, dev, rank, world, backend, ctl):
         torch.cuda.synchronize()
         return None
 
-    for name, npts in (("weak_2^20_per_gpu", nm), ("strong_2^20_total", m.msm_shard_range(nm, world, rank)[1])):
+    for name, npts in (("weak_2^%d_per_gpu" % log2_points, nm), ("strong_2^%d_total" % log2_points, m.msm_shard_range(nm, world, rank)[1])):
         res = one(npts)
         dist.barrier()
         torch.cuda.synchronize()
@@ -382,6 +382,7 @@ def main():
                     help="mode of the contexts of the timed region (mi355_bls_ctx_set_cooperative): auto = throughput when several batches are in flight")
     ap.add_argument("--no-one-caller", action="store_true", help="skip the one-blocking-caller measurements after the timed region (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (shards + collective) even with one rank")
+    ap.add_argument("--msm-log2", type=int, default=20, help="N > 1: log2 of the points per GPU of the multi-GPU MSM rows (tests pass a small value)")
     ap.add_argument("--exchange", choices=["device", "host"], default=os.environ.get("BENCH_EXCHANGE", "device"),
                     help="N > 1: all_gather of device-resident shard blobs (RCCL, no host round trip) or of host bytes")
     a = ap.parse_args()
@@ -424,6 +425,10 @@ def main():
     n_total, nthreads, lo, hi, throughput_mode = run.n_total, run.nthreads, run.lo, run.hi, run.throughput_mode
     rnd = hashlib.sha256(b"Mr F was here").digest()
     cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=nthreads, device=local)      # the one blocking caller: latency mode
+    if os.environ.get("BENCH_TEST_DIE_RANK") == str(rank) and world > 1:
+        # TEST HOOK (tests/test_gpu_bench_multirank.py): this rank dies after its set-up, the others are left inside the first
+        # exchange - spawn_ranks must notice, end them and exit non-zero
+        os._exit(3)
     dt = run.timed(a.steps, a.warmup)
     exchange, stage_acc, gen_s = run.exchange, run.stage_acc, run.gen_s
 
@@ -519,14 +524,17 @@ def main():
         run.close()
         del run, caches, d_sets
         torch.cuda.synchronize()
-        multi = {"g1_msm": msm_rows_sharded(m, cache, dev, rank, world, backend, ctl)}
+        multi = {"g1_msm": msm_rows_sharded(m, cache, dev, rank, world, backend, ctl, a.msm_log2)}
         if world == 8:
-            # BASELINE config 5: 2^20 tuples across 8 GPUs = 131 072 per GPU
-            run5 = ShardedRun(m, a, dev, local, rank, world, backend, ctl, 131072, True)
-            k5 = max(6, min(a.steps, 20))
-            dt5 = run5.timed(k5, 3)
-            multi["config5_batchVerify_2^20"] = {"verifications_per_s": run5.n_total * k5 / dt5, "ms_per_step": dt5 / k5 * 1e3, "global_batch": run5.n_total,
-                                                 "tuples_per_gpu": 131072, "steps": k5, "exchange": run5.exchange}
+            # BASELINE config 5: 2^20 tuples across 8 GPUs = 131 072 per GPU = twice the headline batch (the row follows --batch so that a
+            # dry run of this code path with small batches stays cheap: tests/test_gpu_bench_multirank.py)
+            n5 = 2 * a.batch
+            run5 = ShardedRun(m, a, dev, local, rank, world, backend, ctl, n5, True)
+            k5 = max(2, min(a.steps, 20)) if a.batch < 65536 else max(6, min(a.steps, 20))
+            dt5 = run5.timed(k5, min(3, a.warmup))
+            multi["config5_batchVerify_2^20" if n5 == 131072 else "config5_shape_batchVerify"] = {
+                "verifications_per_s": run5.n_total * k5 / dt5, "ms_per_step": dt5 / k5 * 1e3, "global_batch": run5.n_total, "tuples_per_gpu": n5, "steps": k5,
+                "exchange": run5.exchange}
             run5.close()
         if rank == 0:
             out["multi_gpu"] = multi

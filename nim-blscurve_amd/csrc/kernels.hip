@@ -1691,6 +1691,14 @@ struct mi355_bls_ctx {
     hipStream_t side = nullptr;      // fork / join stream of latency-mode calls (independent stages beside each other)
     uint32_t* d_export = nullptr;
     hipEvent_t ev[9] = {};
+    // A batch larger than the workspace runs in slices; the slices of ONE call are pipelined over up to three workspaces - this
+    // context's and two internal ones (lanes), created at the first sliced call, each on a stream of its own - like the batches of
+    // three callers (run_shard).
+    mi355_bls_ctx* lane[2] = {nullptr, nullptr};
+    hipStream_t lane_st[2] = {nullptr, nullptr};
+    hipEvent_t lane_ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_sl0 = nullptr, ev_blind[3] = {nullptr, nullptr, nullptr};
+    bool is_lane = false;
     hipEvent_t ev_hm = nullptr, ev_lp = nullptr;   // inside the hash stage (after k_hash_map) and the line-product stage (after k_lineprod)
     hipEvent_t ev_s0 = nullptr, ev_l0 = nullptr;   // start of the signature side (on its stream) and of the tuple pairs' Miller lines: the stage timers of forked calls
     float ktimes[4] = {};         // k_hash_map, k_hash_clear, k_lineprod, k_lineprod2 of the last batch call
@@ -1730,6 +1738,17 @@ extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (int k = 0; k < 2; k++) {
+        if (c->lane_st[k]) {
+            (void)hipStreamSynchronize(c->lane_st[k]);
+            (void)hipStreamDestroy(c->lane_st[k]);
+        }
+        if (c->lane_ev[k]) (void)hipEventDestroy(c->lane_ev[k]);
+        if (c->lane[k]) mi355_bls_ctx_destroy(c->lane[k]);
+    }
+    if (c->ev_sl0) (void)hipEventDestroy(c->ev_sl0);
+    for (auto& e : c->ev_blind)
+        if (e) (void)hipEventDestroy(e);
     void* bufs[] = {c->d_sets, c->d_rnd, c->d_r, c->d_H, c->d_M, c->d_P, c->d_lines, c->d_sig_pts, c->d_sig_sorted, c->d_sig_hist, c->d_sig_consts, c->d_agg, c->d_agg1, c->d_msg, c->d_comp, c->d_status, c->d_lpart, c->d_L, c->d_states, c->d_gt, c->d_gt_fv, c->d_carry, c->d_blob, c->d_flags, c->d_export};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -2009,15 +2028,19 @@ static int enqueue_line_products(mi355_bls_ctx* c, uint32_t npairs, hipStream_t 
 // whole-chip kernel).  A small batch in latency mode runs the last two on the context's side stream beside the hashing: they
 // are all latency-bound there (a few waves each), so this takes about a millisecond off the call.
 static int run_pairs(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, hipStream_t st);
-static int run_slice(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
-                     size_t tuple_base, size_t n, int serial, size_t serial_off, uint32_t slice, hipStream_t st) {
+// c: the workspace this slice runs in (the caller's context or one of its lanes); p: the caller's context, which holds what the slices
+// of one call share - the random bytes, the carried chain state, the host-computed serial chain.  blind_done (may be null) is
+// recorded behind the blinding kernel: the next slice's chains continue from the state this one leaves.
+static int run_slice(mi355_bls_ctx* c, mi355_bls_ctx* p, const uint8_t* d_sets, size_t n_total, uint32_t nchunks, uint32_t chunk_lo, uint32_t chunk_cnt,
+                     size_t tuple_base, size_t n, int serial, size_t serial_off, uint32_t slice, hipStream_t st, hipEvent_t blind_done) {
     HIPCHK(hipEventRecord(c->ev[0], st));
     if (serial) {
-        HIPCHK(hipMemcpyAsync(c->d_r, c->h_r.data() + serial_off, n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->d_r, p->h_r.data() + serial_off, n * 8, hipMemcpyHostToDevice, st));
     } else {
-        k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, n, c->d_carry + 8 * (slice & 1),
-                                                                c->d_carry + 8 * ((slice + 1) & 1), c->d_r);
+        k_blind<<<(chunk_cnt + WAVE - 1) / WAVE, WAVE, 0, st>>>(p->d_rnd, n_total, nchunks, chunk_lo, chunk_cnt, tuple_base, n, p->d_carry + 8 * (slice & 1),
+                                                                p->d_carry + 8 * ((slice + 1) & 1), c->d_r);
     }
+    if (blind_done) HIPCHK(hipEventRecord(blind_done, st));
     return run_pairs(c, d_sets, n, st);
 }
 // Everything behind the blinding scalars (d_r[0 .. n) are ready on `st`): hashing, [r]PK, the signature side, Miller lines, line
@@ -2110,6 +2133,27 @@ static inline uint32_t chunk_of_tuple(size_t n_total, uint32_t B, size_t t) {
     return (uint32_t)(t < cut ? t / (base + 1) : rem + (t - cut) / base);
 }
 
+__global__ void k_or_flag(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && src[0]) atomicOr(dst, src[0]);
+}
+// the internal workspaces of pipelined slices: same device, same capacity, throughput mode (no fork streams: the slices overlap each other)
+static int ensure_lanes(mi355_bls_ctx* c, int want) {
+    if (!c->ev_sl0) HIPCHK(hipEventCreateWithFlags(&c->ev_sl0, hipEventDisableTiming));
+    for (auto& e : c->ev_blind)
+        if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int k = 0; k < want && k < 2; k++) {
+        if (c->lane[k]) continue;
+        mi355_bls_ctx* x = nullptr;
+        int rc = mi355_bls_ctx_create(&x, c->device, c->cap);
+        if (rc) return rc;
+        x->is_lane = true;
+        x->coop = false;
+        c->lane[k] = x;
+        HIPCHK(hipStreamCreateWithFlags(&c->lane_st[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+    }
+    return 0;
+}
 // A shard = chunks [chunk_lo, chunk_lo + chunk_cnt) = tuples [tuple_base, tuple_base + n) of the global batch -> committed state in
 // d_states slot 0.  The reference's cache holds per-thread pairing contexts only and accepts any input.len
 // (bls_batch_verifier.nim:108-119,141); here the workspace is sized for `cap` tuples, so a larger shard is processed in
@@ -2134,22 +2178,67 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* src_dev, const uint8_t* sr
         host_serial_chain(rnd, n, c->h_r.data());
     }
     const size_t nslices = (n + c->cap - 1) / c->cap;
+    if (nslices == 1) {
+        const uint8_t* d = src_dev ? src_dev : c->d_sets;
+        if (!src_dev) HIPCHK(hipMemcpyAsync(c->d_sets, src_host, n * 320, hipMemcpyHostToDevice, st));
+        uint32_t c_lo = serial ? 0 : chunk_of_tuple(n_total, nchunks, tuple_base), c_hi = serial ? 1 : chunk_of_tuple(n_total, nchunks, tuple_base + n - 1) + 1;
+        return run_slice(c, c, d, n_total, nchunks, c_lo, c_hi - c_lo, tuple_base, n, serial, 0, 0, st, nullptr);
+    }
+    // ---- several slices: pipelined over the workspaces of this context and of up to two lanes, each on its own stream.  Slice i starts
+    // when slice i - 1 (on another workspace) has finished hashing and its public-key multiplications, exactly as bench.py staggers the
+    // batches of three callers (`after`): the slices then sit at different stages and the serial tail of one runs beside the wide
+    // kernels of another.  What orders them: the blinding chains (a chunk cut by a slice boundary continues from the state the previous
+    // slice's k_blind left: ev_blind), and each workspace's own stream.  Every workspace keeps the running product of ITS slices in
+    // slot 1 of its d_states; at the end the lanes' products are copied over and multiplied in (an Fp12 product commutes).  The last
+    // slice always runs in this context's own workspace, so fetch_stage(0..3) shows it as before.
+    const int nl = nslices >= 3 ? 3 : 2;                      // workspaces used, this context's included
+    {
+        int rcl = ensure_lanes(c, nl - 1);
+        if (rcl) return rcl;
+    }
+    HIPCHK(hipEventRecord(c->ev_sl0, st));                     // rnd uploaded, flags cleared
+    for (int k = 0; k < nl - 1; k++) {
+        mi355_bls_ctx* x = c->lane[k];
+        x->num_threads = c->num_threads;
+        x->dst = c->dst;
+        x->xmd = c->xmd;
+        HIPCHK(hipStreamWaitEvent(c->lane_st[k], c->ev_sl0, 0));
+        HIPCHK(hipMemsetAsync(x->d_flags, 0, 12, c->lane_st[k]));
+    }
+    bool used[3] = {false, false, false};
+    mi355_bls_ctx* prev = nullptr;
     size_t done = 0;
     for (uint32_t slice = 0; done < n; slice++) {
         size_t left = nslices - slice, cnt = (n - done + left - 1) / left;          // balanced: never a sliver at the end
         size_t t0 = tuple_base + done;
         uint32_t c_lo = serial ? 0 : chunk_of_tuple(n_total, nchunks, t0), c_hi = serial ? 1 : chunk_of_tuple(n_total, nchunks, t0 + cnt - 1) + 1;
-        const uint8_t* d = src_dev ? src_dev + 320 * done : c->d_sets;
-        if (!src_dev) HIPCHK(hipMemcpyAsync(c->d_sets, src_host + 320 * done, cnt * 320, hipMemcpyHostToDevice, st));
-        int rc = run_slice(c, d, n_total, nchunks, c_lo, c_hi - c_lo, t0, cnt, serial, done, slice, st);
+        const int L = (int)((nslices - 1 - slice) % (size_t)nl);                    // the last slice on this context's own workspace
+        mi355_bls_ctx* x = L ? c->lane[L - 1] : c;
+        hipStream_t sx = L ? c->lane_st[L - 1] : st;
+        if (slice) {
+            if (!serial) HIPCHK(hipStreamWaitEvent(sx, c->ev_blind[(slice - 1) % 3], 0));       // the chain state this slice continues from
+            if (prev != x) HIPCHK(hipStreamWaitEvent(sx, prev->ev[3], 0));                      // stagger: behind the previous slice's hashing and [r]PK
+        }
+        const uint8_t* d = src_dev ? src_dev + 320 * done : x->d_sets;
+        if (!src_dev) HIPCHK(hipMemcpyAsync(x->d_sets, src_host + 320 * done, cnt * 320, hipMemcpyHostToDevice, sx));
+        int rc = run_slice(x, c, d, n_total, nchunks, c_lo, c_hi - c_lo, t0, cnt, serial, done, slice, sx, c->ev_blind[slice % 3]);
         if (rc) return rc;
-        if (nslices > 1) k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 1, slice ? 1 : 0, slice ? 0 : -1);
+        k_state_mul<<<1, TAIL_THREADS, 0, sx>>>(x->d_states, 1, used[L] ? 1 : 0, used[L] ? 0 : -1);
+        used[L] = true;
+        prev = x;
         done += cnt;
     }
-    if (nslices > 1) {
-        k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 0, 1, -1);
-        HIPCHK(hipGetLastError());
+    for (int k = 0; k < nl - 1; k++) {
+        if (!used[k + 1]) continue;
+        mi355_bls_ctx* x = c->lane[k];
+        HIPCHK(hipEventRecord(c->lane_ev[k], c->lane_st[k]));
+        HIPCHK(hipStreamWaitEvent(st, c->lane_ev[k], 0));
+        HIPCHK(hipMemcpyAsync(c->d_states + (size_t)(2 + k) * 144, x->d_states + 144, 576, hipMemcpyDeviceToDevice, st));
+        k_or_flag<<<1, 1, 0, st>>>(c->d_flags, x->d_flags);                         // an infinity public key in a lane's slice fails the call
+        k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 1, 1, 2 + k);
     }
+    k_state_mul<<<1, TAIL_THREADS, 0, st>>>(c->d_states, 0, 1, -1);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -2914,6 +3003,17 @@ extern "C" int mi355_bls_fast_aggregate_verify(mi355_bls_ctx* c, const void* pks
 // blst_p1s_mult_pippenger / blst_p2s_mult_pippenger replacement (host side)
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t MSM_SEG = 16;
+// buckets per running-sum segment of k_pip_segred: shorter running sums once they still fill the chip.  MI355_BLS_MSM_SEG (4, 8, 16) overrides
+// it for experiments (tools/msm_quick.sh).
+static uint32_t msm_seg_len(uint32_t cbk) {
+    static const uint32_t forced = [] {
+        const char* e = getenv("MI355_BLS_MSM_SEG");
+        uint32_t v = e ? (uint32_t)atoi(e) : 0;
+        return (v == 4 || v == 8 || v == 16) ? v : 0u;
+    }();
+    if (forced && (1u << cbk) >= forced) return forced;
+    return cbk >= 12 ? 8u : MSM_SEG;
+}
 
 // Window plan for npoints x nbits: about log2(n) - 3 bits per window (signed digits: 2^(c-1) buckets), widths balanced.
 static pip_win pip_plan(size_t npoints, size_t nbits) {
@@ -2998,7 +3098,7 @@ static int msm_enqueue(mi355_bls_ctx* c, msm_ws* m, const void* d_points, size_t
     pip_win W = pip_plan(npoints, nbits);
     int rc = msm_reserve(c, m, npoints, W, AFFB);
     if (rc) return rc;
-    uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, seg = W.cbk >= 12 ? 8u : MSM_SEG, segs_per_win = (1u << W.cbk) / seg,      // shorter running sums once they still fill the chip
+    uint32_t n = (uint32_t)npoints, nw = W.nwin, total = nw << W.cbk, seg = msm_seg_len(W.cbk), segs_per_win = (1u << W.cbk) / seg,      // shorter running sums once they still fill the chip
              nseg = nw * segs_per_win;
     const uint8_t* pts = (const uint8_t*)d_points;
     const uint8_t* sc = (const uint8_t*)d_scalars;

@@ -57,6 +57,40 @@ def test_bench_spawns_its_own_ranks():
     assert msm["strong_2^20_total"]["points_total"] == 1 << 20
 
 
+def test_eight_ranks_dry_run_on_one_gpu():
+    """The `--gpus 8` command the driver runs on an 8-GPU node, as a dry run on ONE device (eight rank processes share device 0 and
+    exchange over gloo; 4 096 tuples per rank): the headline loop, the multi-GPU MSM rows and the config-5 row (twice the batch per
+    GPU, the shape of BASELINE config 5) all execute, so that the first real 8-GPU run is not also the first run of this code path.
+    No scaling number is read from this."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_ALL_ON_DEVICE0="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu", "--msm-log2", "14"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * 4096 and d["value"] > 0
+    c5 = d["multi_gpu"]["config5_shape_batchVerify"]
+    assert c5["tuples_per_gpu"] == 8192 and c5["global_batch"] == 8 * 8192 and c5["verifications_per_s"] > 0
+    assert d["multi_gpu"]["g1_msm"]["weak_2^14_per_gpu"]["points_total"] == 8 << 14
+
+
+def test_a_dying_rank_fails_the_run():
+    """One of the rank processes `bench.py --gpus 2` started dies after its set-up (test hook BENCH_TEST_DIE_RANK): the parent must end
+    the other rank, report which rank failed and exit non-zero well within its timeout - not hang in the first exchange."""
+    import time
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_ALL_ON_DEVICE0="1", BENCH_TEST_DIE_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu", "--no-aux"]
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 1, (p.returncode, p.stderr[-2000:])
+    assert "rank 1 exited with code 3" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]            # no result line from a failed run
+    assert time.time() - t0 < 300
+
+
 def test_bench_refuses_a_world_that_does_not_match_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
