@@ -51,6 +51,10 @@ MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 26308
 MAD_ISSUE_CYCLES = 4.0          # one wave64 VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md, issue cost table)
 CLOCK_HZ = 2.4e9                # peak engine clock; under this load the chip sustains less (DVFS), see DESIGN.md section 4
 MAD_PEAK_MEASURED = 256 * 4 * 64 / 2.28e-9      # multiply-adds/s the chip issues in the micro-benchmark (profiles/r01_ubench_valu.txt)
+# The CEILING for this arithmetic: back-to-back lazily reduced dot products (588 multiply-adds + 69 other instructions each) with no
+# caller code at all, every SIMD busy (tools/ubench_fp2chain.hip, profiles/r04_ubench_fp2chain.txt): 30.39 T multiply-adds/s - the
+# chip holds 2.17 GHz under that stream and issues an instruction per 4.09 cycles
+MAD_CEILING = 30.39e12
 # which stage timer (HIP events inside the library) measures which single kernel
 KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
 
@@ -486,6 +490,8 @@ def main():
             "stage_ms_one_caller": one.get("stage_ms_one_caller"),
             "value_host_buffers": one.get("value_host_buffers"),
             "ms_host_buffers": one.get("ms_host_buffers"),
+            "value_one_caller_sliced": one.get("value_one_caller_sliced"),
+            "ms_one_caller_sliced_2^20": one.get("ms_one_caller_sliced_2^20"),
             "roofline": {"bound": "hbm", "bound_actual": "int_mad", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
                          "kernel_ms_timed_region": dom_ms, "kernel_ms_alone": alone[dom],
@@ -499,6 +505,9 @@ def main():
                                               "2.4 GHz / 4 cycles per v_mad_i64_i32",
                                      "per_kernel_frac_alone": {k: MAD_PER_TUPLE[k] * n / (alone[k] * 1e-3) / mad_peak
                                                                for k in alone if k in MAD_PER_TUPLE and alone[k] > 0},
+                                     "ceiling": {"achievable": MAD_CEILING / 1e12, "frac_of_peak": MAD_CEILING / mad_peak, "achieved_over_ceiling": mad_achieved / MAD_CEILING,
+                                                 "source": "tools/ubench_fp2chain.hip (profiles/r04_ubench_fp2chain.txt): back-to-back dot-product bodies, zero caller "
+                                                           "code, one wave per SIMD on every SIMD"},
                                      "peak_measured": MAD_PEAK_MEASURED / 1e12,
                                      "frac_of_measured": mad_achieved / MAD_PEAK_MEASURED,
                                      "peak_measured_note": "tools/ubench_valu.hip on this chip (profiles/r01_ubench_valu.txt): a stream of independent "
@@ -590,6 +599,23 @@ def one_caller_rows(m, cache, cache_tp, stream, d_sets, n, n_total, lo, hi, rnd,
         dt = (time.perf_counter() - t0) / reps
         out["ms_host_buffers"] = dt * 1e3
         out["value_host_buffers"] = n / dt
+        # ONE blocking call on a batch 16 x the context's capacity (the reference's cache accepts any input.len,
+        # bls_batch_verifier.nim:108-119,141): the library runs the slices pipelined over three internal workspaces, so the
+        # blocking caller gets the pipelined rate, not the one-caller rate.  The 16 copies of the resident batch form one valid
+        # batch of 16 n tuples (every tuple keeps its own blinding scalar).
+        if n == 65536:
+            try:
+                big = d_sets.repeat(16)
+                assert cache_tp.verify_device(big.data_ptr(), 16 * n, rnd, stream.cuda_stream)         # warm-up: creates the lanes
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    assert cache_tp.verify_device(big.data_ptr(), 16 * n, rnd, stream.cuda_stream)
+                dt = (time.perf_counter() - t0) / 2
+                out["ms_one_caller_sliced_2^20"] = dt * 1e3
+                out["value_one_caller_sliced"] = 16 * n / dt
+                del big
+            except torch.OutOfMemoryError:
+                out["value_one_caller_sliced"] = None
     return out
 
 

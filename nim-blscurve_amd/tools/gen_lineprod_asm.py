@@ -200,7 +200,7 @@ def text_of(t):
     if op == "movi":
         return "v_mov_b32_e32 v%d, 0x%x" % (t[1], t[2])
     if op == "mov":
-        return "v_mov_b32_e32 v%d, v%d" % (t[1], t[2])
+        return "v_mov_b32_e64 v%d, v%d" % (t[1], t[2])                 # 8-byte encoding: the stream stays 8-byte aligned without the post-pass too
     if op == "call":
         return "s_swappc_b64 s[%d:%d], s[%d:%d]" % (S_RET, S_RET + 1, S_SUB, S_SUB + 1)
     if op == "raw":
@@ -411,13 +411,38 @@ def selftest(rounds=3):
           % (n, len(g.ins), len(sub.ins), mads, 100.0 * mads / n))
 
 
+def ubench_text(bodies=4):
+    """tools/ubench_fp2chain.hip: `bodies` lazily reduced dot products a0 b0 + a1 b1 (fp.hpp fp_dot2_core: 588 multiply-adds + 68
+    bookkeeping instructions each, half an Fp2 product) back to back with NO caller code at all - the instruction mix the field
+    multipliers cannot do better than; every body's result feeds the next one's operand so that nothing can be dropped"""
+    global L_BASE, X_BASE, M_BASE, ACC
+    keep = (L_BASE, X_BASE, M_BASE, ACC)
+    T = ["s_mov_b32 s%d, 0x%x" % (S_P + i, PL[i]) for i in range(NL)]
+    T += ["s_mov_b32 s%d, 0x%x" % (S_N0, N0), "s_mov_b32 s%d, 0x%x" % (S_MASK, MASK)]
+    g = Gen()
+    xa, ya, xb, yb = ([b + i for i in range(NL)] for b in (0, 14, 28, 42))
+    M_BASE, ACC = 56, 70
+    for k in range(bodies):
+        g.dot([(xa, ya), (xb, yb)], xa if k % 2 else xb)
+    T += [text_of(t) for t in g.ins]
+    L_BASE, X_BASE, M_BASE, ACC = keep
+    return T
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--selftest", action="store_true")
+    ap.add_argument("--ubench-dot2", type=int, default=0, help="emit N back-to-back dot2 bodies (tools/ubench_fp2chain.hip) instead of the kernel loop")
     ap.add_argument("-o", "--out")
     a = ap.parse_args()
     if a.selftest:
         selftest()
+        return
+    if a.ubench_dot2:
+        lines = ["\\t" + l for l in ubench_text(a.ubench_dot2)]
+        txt = "// GENERATED by nim-blscurve_amd/tools/gen_lineprod_asm.py --ubench-dot2 %d\n#define UBENCH_BODY \\\n" % a.ubench_dot2
+        txt += "\n".join('    "%s\\n" \\' % l for l in lines) + "\n\n"
+        open(a.out, "w").write(txt) if a.out else sys.stdout.write(txt)
         return
     lines = [l if l.startswith(".L") else "\\t" + l for l in kernel_text()]      # instructions indented: tools/align_isa.py recognises them that way
     txt = ("// GENERATED by nim-blscurve_amd/tools/gen_lineprod_asm.py -- do not edit.\n"
