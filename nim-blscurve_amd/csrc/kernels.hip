@@ -2303,6 +2303,26 @@ static int verify_common(mi355_bls_ctx* c, const uint8_t* d_sets, const uint8_t*
     return verify_wait(c);
 }
 
+// where a batch submitted with `after` starts: behind that batch's hashing and public-key multiplications (ev[3]).
+// MI355_BLS_CHAIN_EV = hm | clear | pk | sig | lines | lp moves the point (experiments: tools/abn.sh).
+static hipEvent_t chain_event(mi355_bls_ctx* a) {
+    static const int which = [] {
+        const char* e = getenv("MI355_BLS_CHAIN_EV");
+        if (!e) return 2;
+        const char* names[] = {"hm", "clear", "pk", "sig", "lines", "lp"};
+        for (int i = 0; i < 6; i++)
+            if (!strcmp(e, names[i])) return i;
+        return 2;
+    }();
+    switch (which) {
+        case 0: return a->ev_hm;
+        case 1: return a->ev[2];
+        case 3: return a->ev[4];
+        case 4: return a->ev[5];
+        case 5: return a->ev_lp;
+        default: return a->ev[3];
+    }
+}
 extern "C" int mi355_bls_batch_submit_device(mi355_bls_ctx* c, const void* d_sets, size_t n, const uint8_t rnd[32], void* stream, mi355_bls_ctx* after) {
     if (after && after != c && after->wide_recorded) {
         // software pipelining: this batch starts when `after`'s batch has finished hashing and its public-key multiplications (the best of the
@@ -2310,7 +2330,7 @@ extern "C" int mi355_bls_batch_submit_device(mi355_bls_ctx* c, const void* d_set
         // at different stages and the serial tail of one always runs beside whole-chip kernels of another (batches that
         // start together stay in phase: their tails coincide and leave the chip idle)
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, after->ev[3], 0));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, chain_event(after), 0));
     }
     return verify_enqueue(c, (const uint8_t*)d_sets, nullptr, n, rnd, 0, (hipStream_t)stream);
 }

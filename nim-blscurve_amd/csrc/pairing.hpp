@@ -51,9 +51,16 @@ BLS_HD g2_proj g2_to_proj(const g2_jac& q) {
 // T <- 2T, returns the tangent line at T evaluated at P, times 2 Y Z^2 (an Fp2 factor):
 //   (Y^2 - 3b' Z^2)  -  3 X^2 * xp v  +  2 Y Z * yp vw          with b' = 4 xi
 //   X3 = 2 X Y (B - 3E), Y3 = (B + 3E)^2 - 12 E^2, Z3 = 4 B H;  B = Y^2, C = Z^2, E = 3 b' C, H = 2 Y Z
+// (Round 4 tried the FIRST squaring of a step expanded in place, -DBLS_LINES_FIRST_INL: the 24 line stores of the previous step are in
+// flight when a step begins and a callee opens with s_waitcnt vmcnt(0).  No gain: k_lines' 8 % of non-issuing wave cycles are the 30
+// instruction-fetch restarts of its 15 calls per step and a 43 KB hot loop, not store drains - profiles/r04_ab/ab_lines_first_inline.txt.)
 template <class M>
 BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
+#if defined(BLS_LINES_FIRST_INL)
+    fp2 B = fp2_sqr_inl(t.y);
+#else
     fp2 B = m.sqr(t.y);
+#endif
     fp2 C = m.sqr(t.z);
     fp2 X2 = m.sqr(t.x);
     fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));                       // 4 xi C   (2 -> 4 units, carry, 2)
