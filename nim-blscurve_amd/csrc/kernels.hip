@@ -424,7 +424,7 @@ __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, u
 // clear_cofactor_g2 (h2c.hpp) with the two 63-doubling chains lane-parallel; the chain accumulator stays in registers (inlined
 // loop), the base point waits in the registers of the team (every lane holds it anyway)
 __device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
-    g2_park_regs park;
+    g2_park_regs park;                 // (parking the base in LDS as k_hash_clear does leaves these kernels' spill counts unchanged: tried in round 4)
     team_lanes8 team{gbase, role};
     auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
     auto dbl_run = [&](const g2_jac& a, int n) {
