@@ -424,18 +424,15 @@ __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, u
 // clear_cofactor_g2 (h2c.hpp) with the two 63-doubling chains lane-parallel; the chain accumulator stays in registers (inlined
 // loop), the base point waits in the registers of the team (every lane holds it anyway)
 __device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
-    g2_park_regs park;                 // (parking the base in LDS as k_hash_clear does leaves these kernels' spill counts unchanged: tried in round 4)
+#if defined(BLS_COOP_PARK_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 coop_park_slots[3 * BLS_LDS_SLOT];
+    g2_park_lds park{(bls_lds_u32x4*)coop_park_slots};
+#else
+    g2_park_regs park;
+#endif
     team_lanes8 team{gbase, role};
     auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
-    auto dbl_run = [&](const g2_jac& a, int n) {
-        g2_jac r = a;
-#pragma clang loop unroll(disable)
-        do {
-            r = jac_dbl_team(r, team);
-        } while (--n > 0);
-        return r;
-    };
-    return clear_cofactor_g2_with(p, park, dbl_run, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
+    return clear_cofactor_g2_bits(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
 }
 __device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
