@@ -46,7 +46,7 @@ KERNEL_BYTES = {"k_hash_map": 32 + 2 * 288, "k_hash_clear": 2 * 288 + 288, "k_pk
                 "k_lineprod": 68 * 288}
 # 32x32+64-bit multiply-adds (v_mad_i64_i32 / v_mad_u64_u32) per tuple and kernel of the one-lane-per-tuple pipeline:
 # a census of the real formulas (tests/host_emu: emu_mad_census; tests/test_host_emu.py pins this table to it)
-MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 263081, "k_sig_bucket": 87808, "k_lines": 759997,
+MAD_PER_TUPLE = {"k_hash_map": 680358, "k_hash_clear": 1079568, "k_pkmul": 259357, "k_sig_bucket": 87808, "k_lines": 735301,
                  "k_lineprod": 1119552}
 MAD_ISSUE_CYCLES = 4.0          # one wave64 VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md, issue cost table)
 CLOCK_HZ = 2.4e9                # peak engine clock; under this load the chip sustains less (DVFS), see DESIGN.md section 4

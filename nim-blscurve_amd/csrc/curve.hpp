@@ -37,6 +37,10 @@ BLS_HD fp2 f_carry(const fp2& a) { return fp2_carry(a); }
 // partial reduction (|v| < 0.51p): applied to stored coordinates so value bounds never accumulate
 BLS_HD fp f_red(const fp& a) { return fp_reduce(a); }
 BLS_HD fp2 f_red(const fp2& a) { return fp2_reduce(a); }
+// a b - c d with ONE reduction where the field has a lazily reduced dot product (Fp: fp_dot2, 588 multiply-adds + 68 instead of
+// 2 x (392 + 68) and a subtraction with its carry); Fp2: two products.  Operands: at most 2 limb units each.  Result carried.
+BLS_HD fp f_mul_sub_mul(const fp& a, const fp& b, const fp& c, const fp& d) { return fp_dot2(a, b, fp_neg(c), d); }
+BLS_HD fp2 f_mul_sub_mul(const fp2& a, const fp2& b, const fp2& c, const fp2& d) { return fp2_carry(fp2_sub_nc(fp2_mul(a, b), fp2_mul(c, d))); }
 template <class F>
 BLS_HD F f_zero();
 template <>
@@ -112,6 +116,34 @@ BLS_MID jac<F> jac_dbl_m(const jac<F>& p, const M& m) {
 template <class F>
 BLS_MID jac<F> jac_dbl(const jac<F>& p) { return jac_dbl_m(p, mul_shared{}); }
 
+// The same doubling for G2 with the multiplier bodies in place (the doubling runs of the cofactor clearing) and Y3 as ONE lazily
+// reduced pair: Y3 = E (D - X3) - 8 B^2, so C = B^2 is never formed on its own (D = 4 X B directly):
+//   A = X^2, B = Y^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Z3 = 2 Y Z,
+//   Y3.re = E0 W0 - E1 W1 - [8 (B0 + B1)] (B0 - B1),   Y3.im = E0 W1 + E1 W0 - [8 B0] [2 B1]      (W = D - X3)
+// 3 squarings + 2 products + 2 three-term dot products = 6 272 multiply-adds as before, 12 reductions instead of 14 and none of the
+// (X + B)^2 - A - C and 8 C glue: ~370 instructions fewer per doubling.
+BLS_MID jac<fp2> jac_dbl_lazy(const jac<fp2>& p) {
+    const mul_inplace m{};
+    fp2 A = m.sqr(p.x);
+    fp2 B = m.sqr(p.y);
+    fp2 D = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(m.mul(p.x, B))));                      // 4 X B
+    fp2 E = fp2_carry(fp2_add_nc(fp2_dbl_nc(A), A));
+    fp2 Fq = m.sqr(E);
+    jac<fp2> r;
+    r.x = f_red(fp2_sub_nc(Fq, fp2_dbl_nc(D)));
+    fp2 W = fp2_sub_nc(D, r.x);
+    const fp bs4 = fp_carry(fp_dbl_nc(fp_add_nc(B.c0, B.c1)));                     // 2 (B0 + B1), carried (1 unit)
+    const fp bs8 = fp_carry(fp_dbl_nc(fp_dbl_nc(bs4)));                            // 8 (B0 + B1), carried
+    const fp bd = fp_sub_pos(B.c0, B.c1);                                          // B0 - B1 (canonical limbs: a fresh square)
+    const fp b08 = fp_carry(fp_dbl_nc(fp_dbl_nc(fp_carry(fp_dbl_nc(B.c0)))));      // 8 B0, carried
+    const fp b12 = fp_dbl_nc(B.c1);                                                // 2 B1 (2 units)
+    const fp xr[3] = {E.c0, fp_neg(E.c1), fp_neg(bs8)}, yr[3] = {W.c0, W.c1, bd};
+    const fp xi[3] = {E.c0, E.c1, fp_neg(b08)}, yi[3] = {W.c1, W.c0, b12};
+    r.y = fp2{fp_dotn<3>(xr, yr), fp_dotn<3>(xi, yi)};
+    r.z = fp2_carry(fp2_dbl_nc(m.mul(p.y, p.z)));
+    return r;
+}
+
 // Lane-cooperative doubling for latency-bound chains (one point, or a few, and a whole wave to spend): a TEAM of lanes that all
 // hold the same point computes the independent products of each round of dbl-2009-l in ONE multiplier call, every lane taking
 // one of them, and shares the results.  The formula, its carries and its reductions are jac_dbl's; only who multiplies differs,
@@ -174,7 +206,7 @@ BLS_MID jac<F> jac_add_aff(const jac<F>& p, const aff<F>& q) {
     F V = f_mul(p.x, HH);
     jac<F> r;
     r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
-    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub_nc(V, r.x)), f_mul(p.y, HHH)));
+    r.y = f_mul_sub_mul(rr, f_sub_nc(V, r.x), p.y, HHH);
     r.z = f_mul(p.z, H);   // = 0 when P == -Q
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, jac_from_aff(q), r);
@@ -206,7 +238,7 @@ BLS_MID xyzz<F> xyzz_dbl_aff(const aff<F>& q) {          // q not at infinity
     F M = f_carry(f_add_nc(f_dbl_nc(XX), XX));
     xyzz<F> r;
     r.x = f_red(f_sub_nc(f_sqr(M), f_dbl_nc(S)));
-    r.y = f_carry(f_sub_nc(f_mul(M, f_sub_nc(S, r.x)), f_mul(W, q.y)));
+    r.y = f_mul_sub_mul(M, f_sub_nc(S, r.x), W, q.y);
     r.zz = V;
     r.zzz = W;
     return r;
@@ -226,7 +258,7 @@ BLS_MID xyzz<F> xyzz_add_aff_flag(const xyzz<F>& p, const aff<F>& q, bool q_inf)
     F Q = f_mul(p.x, PP);
     xyzz<F> r;
     r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(R), PPP), f_dbl_nc(Q)));
-    r.y = f_carry(f_sub_nc(f_mul(R, f_sub_nc(Q, r.x)), f_mul(p.y, PPP)));
+    r.y = f_mul_sub_mul(R, f_sub_nc(Q, r.x), p.y, PPP);
     r.zz = f_mul(p.zz, PP);       // = 0 when P == -Q
     r.zzz = f_mul(p.zzz, PPP);
     r = xyzz_select(q_inf, p, r);
@@ -261,7 +293,7 @@ BLS_MID jac<F> jac_add_body(const jac<F>& p, const jac<F>& q) {
     F V = f_mul(U1, HH);
     jac<F> r;
     r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
-    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub_nc(V, r.x)), f_mul(S1, HHH)));
+    r.y = f_mul_sub_mul(rr, f_sub_nc(V, r.x), S1, HHH);
     r.z = f_mul(f_mul(p.z, q.z), H);
     r = jac_select(q_inf, p, r);
     r = jac_select(p_inf, q, r);

@@ -311,6 +311,17 @@ BLS_MID jac<F> jac_dbl_n(const jac<F>& a, int n, const M& m) {
     } while (--n > 0);
     return r;
 }
+#if !defined(BLS_CLEAR_DBL_PLAIN)
+// G2 with the bodies in place: the doubling with the lazily reduced Y3 (curve.hpp jac_dbl_lazy)
+BLS_MID jac<fp2> jac_dbl_n(const jac<fp2>& a, int n, const mul_inplace&) {
+    jac<fp2> r = a;
+#pragma clang loop unroll(disable)
+    do {
+        r = jac_dbl_lazy(r);
+    } while (--n > 0);
+    return r;
+}
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BLS_LAMBDA_INLINE __attribute__((always_inline))
 #else
@@ -324,7 +335,11 @@ BLS_MID g2_jac clear_cofactor_g2_with(const g2_jac& p, Park& park, const M& m) {
 }
 BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
     g2_park_regs park;
-    return clear_cofactor_g2_with(p, park, mul_shared{});
+#if defined(__HIP_DEVICE_COMPILE__)
+    return clear_cofactor_g2_with(p, park, mul_shared{});      // the out-of-line form (k_hash_var, the signer): compact code on the shared multipliers
+#else
+    return clear_cofactor_g2_with(p, park, BLS_CLEAR_MUL{});   // host (tests/host_emu, bounds tracker, census): the formulas k_hash_clear runs
+#endif
 }
 
 BLS_HDN g2_jac hash_to_g2(const uint8_t* msg, uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {

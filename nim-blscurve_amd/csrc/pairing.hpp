@@ -51,6 +51,18 @@ BLS_HD g2_proj g2_to_proj(const g2_jac& q) {
 // T <- 2T, returns the tangent line at T evaluated at P, times 2 Y Z^2 (an Fp2 factor):
 //   (Y^2 - 3b' Z^2)  -  3 X^2 * xp v  +  2 Y Z * yp vw          with b' = 4 xi
 //   X3 = 2 X Y (B - 3E), Y3 = (B + 3E)^2 - 12 E^2, Z3 = 4 B H;  B = Y^2, C = Z^2, E = 3 b' C, H = 2 Y Z
+// a^2 - 12 e^2 in Fp2 as TWO lazily reduced dot products (fp_dot2: one reduction each) instead of two squarings, a quadrupling, a
+// tripling, a subtraction and a partial reduction:  re = (a0 + a1)(a0 - a1) - [4 (e0 + e1)] [3 (e0 - e1)],  im = [2 a0] a1 - [8 e0] [3 e1].
+// a: carried (|v| < 4p per coefficient), e: reduced with canonical limbs (fp2_reduce output).  The scaled operands take one carry step
+// each (the multiplier takes operands of at most 2 limb units).  Result: canonical limbs, |v| < 2p.
+BLS_MID fp2 fp2_sqr_minus_12sqr(const fp2& a, const fp2& e) {
+    const fp e4s = fp_dbl_nc(fp_carry(fp_dbl_nc(fp_add_nc(e.c0, e.c1))));              // 4 (e0 + e1): 4 limb units, carry, 2 units
+    const fp ed = fp_sub_pos(e.c0, e.c1);
+    const fp e3d = fp_carry(fp_add_nc(fp_dbl_nc(ed), ed));                              // 3 (e0 - e1)
+    const fp e8 = fp_dbl_nc(fp_carry(fp_dbl_nc(fp_dbl_nc(e.c0))));                      // 8 e0: 4 units, carry, 2 units
+    const fp e3 = fp_carry(fp_add_nc(fp_dbl_nc(e.c1), e.c1));                           // 3 e1
+    return fp2{fp_dot2(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1), fp_neg(e4s), e3d), fp_dot2(fp_dbl_nc(a.c0), a.c1, fp_neg(e8), e3)};
+}
 // (Round 4 tried the FIRST squaring of a step expanded in place, -DBLS_LINES_FIRST_INL: the 24 line stores of the previous step are in
 // flight when a step begins and a callee opens with s_waitcnt vmcnt(0).  No gain: k_lines' 8 % of non-issuing wave cycles are the 30
 // instruction-fetch restarts of its 15 calls per step and a 43 KB hot loop, not store drains - profiles/r04_ab/ab_lines_first_inline.txt.)
@@ -67,12 +79,16 @@ BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
     fp2 E = fp2_reduce(fp2_add_nc(fp2_dbl_nc(C4), C4));                                 // 12 xi C = 3 b' C   (6 units)
     fp2 F = fp2_add_nc(fp2_dbl_nc(E), E);                                                // 3E, 3 units
     fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.y, t.z)), B), C));           // 2 Y Z
+    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.x, t.y)), X2), B));       // 2 X Y = (X + Y)^2 - X^2 - Y^2: a squaring for a product
+    fp2 x3 = m.mul(XY2, fp2_carry(fp2_sub_nc(B, F)));
+#if defined(BLS_LINES_Y3_SEPARATE)
     fp2 E2 = m.sqr(E);
     fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
     fp2 S = m.sqr(fp2_carry(fp2_add_nc(B, F)));
-    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.x, t.y)), X2), B));       // 2 X Y = (X + Y)^2 - X^2 - Y^2: a squaring for a product
-    fp2 x3 = m.mul(XY2, fp2_carry(fp2_sub_nc(B, F)));
     fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));             // S - 12 E^2
+#else
+    fp2 y3 = fp2_sqr_minus_12sqr(fp2_carry(fp2_add_nc(B, F)), E);                       // (B + 3E)^2 - 12 E^2 with two reductions instead of four
+#endif
     fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(m.mul(B, H))));
     t = g2_proj{x3, y3, z3};
     fp2 BE = fp2_sub_nc(B, E);
