@@ -1623,16 +1623,18 @@ struct msm_ws {
     uint8_t* d_sc = nullptr;
     uint32_t* pts_int = nullptr;
     uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr, *part = nullptr, *shist = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_bucketed = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_bucketed = nullptr, ev_join = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t gs3 = nullptr;        // third window group's stream (the context's main and side streams carry the first two)
     uint4 *buckets = nullptr, *segout = nullptr;
 };
 static void msm_free(msm_ws* m) {
     void* b[] = {m->d_pts, m->d_sc, m->pts_int, m->hist, m->offs, m->cursor, m->sorted, m->order, m->chist, m->winout, m->out, m->buckets, m->segout, m->part, m->shist};
     for (void* x : b)
         if (x) (void)hipFree(x);
-    hipEvent_t ev[] = {m->ev_fork, m->ev_bucketed, m->ev_join};
+    hipEvent_t ev[] = {m->ev_fork, m->ev_bucketed, m->ev_join, m->ev_g[0], m->ev_g[1], m->ev_g[2], m->ev_g[3]};
     for (hipEvent_t e : ev)
         if (e) (void)hipEventDestroy(e);
+    if (m->gs3) (void)hipStreamDestroy(m->gs3);
     *m = msm_ws();
 }
 
@@ -3101,6 +3103,8 @@ static int msm_reserve(mi355_bls_ctx* c, msm_ws* m, size_t n, const pip_win& W, 
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_bucketed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    for (int g = 0; g < 4; g++) HIPCHK(hipEventCreateWithFlags(&m->ev_g[g], hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&m->gs3, hipStreamNonBlocking));
     m->cap_n = cb;
     m->cap_total = ct;
     return 0;
@@ -3164,34 +3168,49 @@ static int msm_enqueue(mi355_bls_ctx* c, msm_ws* m, const void* d_points, size_t
     // accumulation of the low group and only the short chains of the low windows are left at the end.  More groups lose more
     // in the bucket kernels' tails than they hide.  Large inputs only: a small MSM is latency-bound in every stage.
     const bool split = allow_split && c->side && nw >= 4 && (size_t)n * nw >= ((size_t)1 << 22);
-    uint32_t cut[3] = {nw, 0, 0}, ngroups = 1;                      // groups [cut[g + 1], cut[g]), from the high windows down
+    // Groups [cut[g + 1], cut[g]) from the high windows down: two halves.  MI355_BLS_MSM_CUTS="a" or "a,b" (window indices, descending)
+    // moves the cut or makes three groups for experiments (tools/msm_cuts.sh).  Measured at 2^20 x 255 bits, 16 windows
+    // (profiles/r04_ab/msm_cuts.txt): cuts 5 .. 10 are within the noise of 8; three groups (10,4 / 11,5 / 12,6 / 9,3), whose last
+    // group's exposed reduction is shorter, are 1 - 3 % SLOWER alone and 10 % slower with two MSMs in flight - every extra group's
+    // bucket kernel has its own tail and shares the chip with one more reduction.
+    uint32_t cut[5] = {nw, 0, 0, 0, 0}, ngroups = 1;
     if (split) {
-        cut[1] = nw / 2;
+        static const char* e = getenv("MI355_BLS_MSM_CUTS");
+        uint32_t a = nw / 2, b = 0;
+        if (e) {
+            a = (uint32_t)atoi(e);
+            const char* q = strchr(e, ',');
+            b = q ? (uint32_t)atoi(q + 1) : 0;
+            if (a == 0 || a >= nw || b >= a) { a = nw / 2; b = 0; }
+        }
+        cut[1] = a;
         ngroups = 2;
+        if (b) { cut[2] = b; ngroups = 3; }
     }
     // group g runs on its own stream, its bucket kernel behind the bucket kernel of group g - 1: the (latency-bound, few-wave)
     // reduction of a group is dispatched before the next group's bucket kernel and runs beside it.  (Both bucket kernels enqueued at
     // once, the second on a lowest-priority stream so that its waves would only fill the tail of the first - 26 % of a bucket
     // kernel's wave slots idle on average, profiles/r03_pmc_summary_msm.json - was measured 3 % SLOWER: the 512-register reduction
     // waves of the first group then wait for whole SIMDs that the second group's 256-register waves keep half full.)
-    hipStream_t gs[2] = {st, c->side};
-    const bool chain = true;
-    hipEvent_t gev[2] = {m->ev_fork, m->ev_bucketed};
+    hipStream_t gs[3] = {st, c->side, m->gs3};
     count_sort(0, nw, st);
     for (uint32_t g = 0; g < ngroups; g++) order_group(cut[g + 1], cut[g], g, st);
     if (timed) HIPCHK(hipEventRecord(c->ev[1], st));
-    if (ngroups > 1) HIPCHK(hipEventRecord(m->ev_join, st));       // sorted: the other group's stream may start
+    if (ngroups > 2) {                                                   // the third stream starts behind everything enqueued so far
+        HIPCHK(hipEventRecord(m->ev_join, st));
+        HIPCHK(hipStreamWaitEvent(gs[2], m->ev_join, 0));
+    }
     for (uint32_t g = 0; g < ngroups; g++) {
-        if (g) HIPCHK(hipStreamWaitEvent(gs[g], chain ? gev[g - 1] : m->ev_join, 0));
+        if (g) HIPCHK(hipStreamWaitEvent(gs[g], m->ev_g[g - 1], 0));
         bucket_group(cut[g + 1], cut[g], gs[g]);
-        HIPCHK(hipEventRecord(gev[g], gs[g]));
+        HIPCHK(hipEventRecord(m->ev_g[g], gs[g]));
         if (g == 0 && timed) HIPCHK(hipEventRecord(c->ev[2], st));
         reduce_group(cut[g + 1], cut[g], gs[g]);
         if (g == 0 && timed) HIPCHK(hipEventRecord(c->ev[3], st));
     }
     for (uint32_t g = 1; g < ngroups; g++) {
-        HIPCHK(hipEventRecord(gev[g], gs[g]));
-        HIPCHK(hipStreamWaitEvent(st, gev[g], 0));
+        HIPCHK(hipEventRecord(m->ev_g[g], gs[g]));
+        HIPCHK(hipStreamWaitEvent(st, m->ev_g[g], 0));
     }
     k_pip_final<F><<<1, WAVE, 0, st>>>(m->winout, nw, m->out);
     if (timed) HIPCHK(hipEventRecord(c->ev[4], st));
