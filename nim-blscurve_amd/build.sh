@@ -17,7 +17,10 @@ fi
 LLVM=/opt/rocm/lib/llvm/bin
 # --gpu-max-threads-per-block=64: the default launch bound (most kernels are one wave per workgroup; the Fp12 engine kernels and the LDS sort declare their own); this also gives the out-of-line device
 # functions the full 512-register (VGPR+AGPR) budget instead of the 128-VGPR default, so they stop spilling to scratch
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64 $BLS_EXTRA_FLAGS"      # BLS_EXTRA_FLAGS: -D switches of A/B experiments (tools/abn.sh)
+# -amdgpu-dpp-combine=false: on gfx950 the "rev" VOP2 opcodes (v_subrev_u32, v_lshlrev_b32 ...) apply a DPP lane permutation to src1, not to src0 as the
+# ISA documents and as LLVM's DPP combine assumes when it folds a v_mov_b32_dpp into a non-commutative consumer (measured: tools/test_dpp.hip;
+# found through a wrong a - b behind a quad_perm exchange in the G1 lane teams).  The lane exchanges stay plain v_mov_b32_dpp.
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 --gpu-max-threads-per-block=64 -mllvm -amdgpu-dpp-combine=false $BLS_EXTRA_FLAGS"      # BLS_EXTRA_FLAGS: -D switches of A/B experiments (tools/abn.sh)
 B=build
 mkdir -p $B
 python3 tools/gen_lineprod_asm.py -o $B/lineprod_asm.inc         # the hand-allocated inner loop of k_lineprod (included by csrc/kernels.hip)

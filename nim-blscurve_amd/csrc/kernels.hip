@@ -1293,6 +1293,101 @@ __global__ void __launch_bounds__(WAVE) k_pip_segred(const uint4* __restrict__ b
     acc = padd(acc, T);
     soa_st_jac(segout, nseg_total, t, acc);
 }
+// G1 lane teams for the latency-bound reductions: T = 2 or 4 ADJACENT lanes hold the same values; product k of a round runs in lane k mod T
+// (round k / T) and the results are shared with DPP quad permutes (no LDS, no ds_bpermute).  A Jacobian addition costs 5 (T = 4) or 8
+// (T = 2) multiplication times instead of 16, a doubling 3 or 5 instead of 7.  The formulas are jac_add_team / jac_dbl_team (curve.hpp).
+template <int CTRL>
+__device__ __forceinline__ fp fp_quad_perm(const fp& a) {
+    fp r;
+#ifdef BLS_TEAM_SHFL
+    const int q = threadIdx.x & 3, src = (threadIdx.x & ~3) | ((CTRL >> (2 * q)) & 3);
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
+#else
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], CTRL, 0xf, 0xf, true);
+#endif
+    return r;
+}
+template <int T>
+struct team_quad_fp {
+    uint32_t h;                       // threadIdx.x & (T - 1)
+    // value of team lane J, in every lane of the team
+    template <int J>
+    __device__ __forceinline__ fp from(const fp& x) const {
+        if (T == 4) return fp_quad_perm<J * 0x55>(x);
+        return fp_quad_perm<(J ? 0xf5 : 0xa0)>(x);                  // [0,0,2,2] / [1,1,3,3]
+    }
+    __device__ __forceinline__ fp pick4(const fp& a0, const fp& a1, const fp& a2, const fp& a3) const {
+        return fp_select((h & 1) != 0, fp_select((h & 2) != 0, a3, a1), fp_select((h & 2) != 0, a2, a0));
+    }
+    __device__ __forceinline__ void mul4(fp& r0, fp& r1, fp& r2, fp& r3, const fp& a0, const fp& b0, const fp& a1, const fp& b1, const fp& a2, const fp& b2, const fp& a3, const fp& b3) const {
+        if (T == 4) {
+            fp x = fp_mul(pick4(a0, a1, a2, a3), pick4(b0, b1, b2, b3));
+            r0 = from<0>(x); r1 = from<1>(x); r2 = from<2>(x); r3 = from<3>(x);
+        } else {
+            const bool o = h != 0;
+            fp x = fp_mul(fp_select(o, a1, a0), fp_select(o, b1, b0));
+            fp y = fp_mul(fp_select(o, a3, a2), fp_select(o, b3, b2));
+            r0 = from<0>(x); r1 = from<1>(x); r2 = from<0>(y); r3 = from<1>(y);
+        }
+    }
+    __device__ __forceinline__ void mul3(fp& r0, fp& r1, fp& r2, const fp& a0, const fp& b0, const fp& a1, const fp& b1, const fp& a2, const fp& b2) const {
+        fp r3;
+        mul4(r0, r1, r2, r3, a0, b0, a1, b1, a2, b2, a2, b2);
+    }
+    __device__ __forceinline__ void sqr3(fp& r0, fp& r1, fp& r2, const fp& a0, const fp& a1, const fp& a2) const {
+        if (T == 4) {
+            fp x = fp_sqr(pick4(a0, a1, a2, a2));
+            r0 = from<0>(x); r1 = from<1>(x); r2 = from<2>(x);
+        } else {
+            const bool o = h != 0;
+            fp x = fp_sqr(fp_select(o, a1, a0));
+            fp y = fp_sqr(a2);
+            r0 = from<0>(x); r1 = from<1>(x); r2 = y;
+        }
+    }
+    __device__ __forceinline__ void mul2(fp& r0, fp& r1, const fp& a0, const fp& b0, const fp& a1, const fp& b1) const {
+        const bool o = (h & 1) != 0;
+        fp x = fp_mul(fp_select(o, a1, a0), fp_select(o, b1, b0));
+        if (T == 4) { r0 = fp_quad_perm<0xa0>(x); r1 = fp_quad_perm<0xf5>(x); }
+        else { r0 = from<0>(x); r1 = from<1>(x); }
+    }
+    __device__ __forceinline__ void sqr2(fp& r0, fp& r1, const fp& a0, const fp& a1) const {
+        const bool o = (h & 1) != 0;
+        fp x = fp_sqr(fp_select(o, a1, a0));
+        if (T == 4) { r0 = fp_quad_perm<0xa0>(x); r1 = fp_quad_perm<0xf5>(x); }
+        else { r0 = from<0>(x); r1 = from<1>(x); }
+    }
+    __device__ __forceinline__ fp mul1(const fp& a, const fp& b) const { return fp_mul(a, b); }
+};
+// k_pip_segred for G1 with T lanes per segment (T = 2, 4): same sums, same order of additions, the products of every addition and doubling
+// spread over the team.  tcount segments -> tcount * T lanes.
+template <int T>
+__global__ void __launch_bounds__(WAVE) k_pip_segred_team(const uint4* __restrict__ buckets, uint32_t total, uint32_t cbk, uint32_t L, uint32_t nseg_total,
+                                                          uint32_t t0, uint32_t tcount, uint4* __restrict__ segout) {
+    uint32_t lane = blockIdx.x * WAVE + threadIdx.x, t = lane / T;
+    if (t >= tcount) return;            // whole teams leave together (T divides the wave)
+    t += t0;
+    const team_quad_fp<T> team{threadIdx.x & (T - 1)};
+    uint32_t segs_per_win = (1u << cbk) / L;
+    uint32_t w = t / segs_per_win, b0 = (t % segs_per_win) * L;
+    g1_jac S = jac_inf<fp>(), Tt = jac_inf<fp>();
+#pragma clang loop unroll(disable)
+    for (uint32_t j = L; j-- > 0;) {
+        g1_jac B = soa_ld_g1(buckets, total, ((size_t)w << cbk) | (b0 + j));
+        S = jac_add_team(S, B, team);
+        Tt = jac_add_team(Tt, S, team);
+    }
+    g1_jac acc = jac_inf<fp>();
+#pragma clang loop unroll(disable)
+    for (int i = (int)cbk - 1; i >= 0; i--) {
+        acc = jac_dbl_team(acc, team);
+        if ((b0 >> i) & 1) acc = jac_add_team(acc, S, team);
+    }
+    acc = jac_add_team(acc, Tt, team);
+    if ((threadIdx.x & (T - 1)) == 0) soa_st_g1(segout, nseg_total, t, acc);
+}
 // grid (windows, nsplit): partial sums of a window's segment values
 template <class F>
 __global__ void __launch_bounds__(WAVE) k_pip_winpart(const uint4* __restrict__ segout, uint32_t nseg_total, uint32_t segs_per_win, uint32_t w0, uint32_t* __restrict__ part) {
@@ -1624,7 +1719,7 @@ struct msm_ws {
     uint32_t* pts_int = nullptr;
     uint32_t *hist = nullptr, *offs = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *chist = nullptr, *winout = nullptr, *out = nullptr, *part = nullptr, *shist = nullptr;
     hipEvent_t ev_fork = nullptr, ev_bucketed = nullptr, ev_join = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t gs3 = nullptr;        // third window group's stream (the context's main and side streams carry the first two)
+    hipStream_t gs3 = nullptr;        // a third window group's stream (MI355_BLS_MSM_CUTS experiments; the context's main and side streams carry the first two)
     uint4 *buckets = nullptr, *segout = nullptr;
 };
 static void msm_free(msm_ws* m) {
@@ -3154,7 +3249,15 @@ static int msm_enqueue(mi355_bls_ctx* c, msm_ws* m, const void* d_points, size_t
     };
     auto reduce_group = [&](uint32_t w0, uint32_t w1, hipStream_t s) {
         uint32_t t0 = w0 * segs_per_win, tc = (w1 - w0) * segs_per_win;
-        k_pip_segred<F><<<(tc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, seg, nseg, t0, tc, m->segout);
+        // G1: 4 or 2 lanes per segment (lane teams) while the team waves stay well inside the chip's 1024 one-per-SIMD wave slots (<= 960 waves: a
+        // kernel of exactly 1024 such waves finds a few SIMDs taken by the other group's reduction and runs a second round for the stragglers).
+        // profiles/r04_ab/msm_team.txt: 2^14 points 2.70 -> 2.29 ms, 2^16 2.56 -> 2.28, 2^18 3.28 -> 3.10 (two lanes); 2^20 would need 1024 waves per
+        // group and measured 5.2 - 5.4 ms against 5.1 - 5.2: one lane per segment there.  MI355_BLS_MSM_TEAM = 1 / 2 / 4 forces a size.
+        static const int team_forced = getenv("MI355_BLS_MSM_TEAM") ? atoi(getenv("MI355_BLS_MSM_TEAM")) : 0;
+        int team = sizeof(F) != sizeof(fp) ? 1 : (team_forced > 0 ? team_forced : ((size_t)tc * 4 <= 61440 ? 4 : ((size_t)tc * 2 <= 61440 ? 2 : 1)));
+        if (team == 4) k_pip_segred_team<4><<<(tc * 4 + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, seg, nseg, t0, tc, m->segout);
+        else if (team == 2) k_pip_segred_team<2><<<(tc * 2 + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, seg, nseg, t0, tc, m->segout);
+        else k_pip_segred<F><<<(tc + WAVE - 1) / WAVE, WAVE, 0, s>>>(m->buckets, total, W.cbk, seg, nseg, t0, tc, m->segout);
         k_pip_winpart<F><<<dim3(w1 - w0, nsplit), WAVE, 0, s>>>(m->segout, nseg, segs_per_win, w0, m->part);
         k_pip_winsum<F><<<w1 - w0, WAVE, 0, s>>>(m->part, nsplit, W, w0, m->winout);
     };

@@ -13,7 +13,7 @@ cache = m.BatchedBLSVerifierCache.init(max_sets=65536)
 msg = hashlib.sha256(b"Mr F was here").digest()
 rnd = msg
 if "msm" in what:
-    nm = 1 << 20
+    nm = 1 << int(os.environ.get("MSM_LOG2", "20"))
     rng = random.Random(7)
     base = bench.sign_records(m, cache, dev, range(2048), sks=[rng.getrandbits(96) | 1 for _ in range(2048)], msgs=[msg] * 2048)
     dp = base.view(2048, 320)[:, :96].contiguous().repeat(nm // 2048, 1).reshape(-1)

@@ -57,6 +57,7 @@ void emu_g2_dbl(const uint8_t* p, uint8_t* out) { g2_jac_store(out, jac_dbl(g2_j
 void emu_g2_add_team(const uint8_t* a, const uint8_t* b, uint8_t* out) { g2_jac_store(out, jac_add_team(g2_jac_load(a), g2_jac_load(b), team_solo{})); }
 void emu_g1_dbl_team(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl_team(g1_jac_load(p), team_solo{})); }
 void emu_g1_dbl(const uint8_t* p, uint8_t* out) { g1_jac_store(out, jac_dbl(g1_jac_load(p))); }
+void emu_g1_add_team(const uint8_t* a, const uint8_t* b, uint8_t* out) { g1_jac_store(out, jac_add_team(g1_jac_load(a), g1_jac_load(b), team_solo{})); }
 // sum of n affine points (96 / 192 bytes each, all-zero = infinity) with the extended-Jacobian mixed addition of the Pippenger buckets
 void emu_g1_sum_xyzz(const uint8_t* pts, uint32_t n, uint8_t* out) {
     xyzz<fp> acc = xyzz_inf<fp>();

@@ -355,3 +355,9 @@ def test_team_formulas_equal_the_plain_ones(emu):
         for A, B in ((Q, Q2), (Q2, Q), (Q, Q), (Q, g2_aff_to_jac_bytes(o.g2_neg(g2_jac_to_affine(Q)))), (bytes(288), Q), (Q, bytes(288))):
             a, b = call(emu, "emu_g2_add_team", A, B, outlen=288), call(emu, "emu_g2_add", A, B, outlen=288)
             assert g2_jac_to_affine(a) == g2_jac_to_affine(b)
+        # the same in G1 (the lane-team segment reduction of the Pippenger path)
+        p2 = o.g1_mul(o.G1_GEN, rng.randrange(1, o.R))
+        P2 = call(emu, "emu_g1_dbl", g1_aff_to_jac_bytes(p2), outlen=144)
+        for A, B in ((P, P2), (P2, P), (P, P), (P, g1_aff_to_jac_bytes(o.g1_neg(g1_jac_to_affine(P)))), (bytes(144), P), (P, bytes(144)), (bytes(144), bytes(144))):
+            a, b = call(emu, "emu_g1_add_team", A, B, outlen=144), call(emu, "emu_g1_add", A, B, outlen=144)
+            assert g1_jac_to_affine(a) == g1_jac_to_affine(b)
