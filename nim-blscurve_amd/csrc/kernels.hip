@@ -636,7 +636,11 @@ constexpr int C12_NREG = 8;
 // and the 168 items of its second phase in ONE round each: the latency-mode launch (two waves: 8 % slower).  Throughput mode
 // launches two waves: with the chip saturated by 512-register waves a workgroup waits until enough SIMDs of ONE CU have
 // drained, at the head of a hardware queue that other callers' streams share (three waves: +3.6 % per pipelined batch).
+#ifdef BLS_C12_ROW
+constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 192;          // the row engine: 12 rows of 16 lanes
+#else
 constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 128;          // both >= 108: phase 1 is one product per thread
+#endif          // the row engine: 12 rows of 16 lanes (the Karatsuba engine needed >= 108)
 struct c12_lds {
     fp2 r[C12_NREG][6];
     c12_work w;
@@ -645,6 +649,7 @@ struct c12_lds {
     uint32_t steps[N_LINES * 6 * 2 * FP_N];     // the 68 step products, flat basis (46 KB): loaded once, no global load per Horner step
 };
 
+#ifndef BLS_C12_ROW
 // d = a * b (flat basis); d may be a or b.  LDS: any block-shared struct with the registers r[][6] and the work area w.
 template <class LDS>
 __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
@@ -672,6 +677,42 @@ __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
     }
     __syncthreads();
 }
+#else
+// Row engine (c12.hpp, c12r_*; -DBLS_C12_ROW): thread (row = t / 16, q = t % 16) of the 192; d may be a or b (every operand is read before the first
+// barrier, the results are written after it).  The row sum runs on DPP row shifts: lane 15 of a row ends with the sum of its 16 lanes.
+// NOT the default: ~1 200 instructions per product against the Karatsuba engine's ~1 650 on the critical lane, and its best launches are 15 - 20 %
+// faster (k_tail Horner 0.37 ms against 0.43, final exponentiation 1.07 against 1.3), but the SAME launch takes 1.0x / 1.24x / 1.4x / 1.55x that
+// depending on the CU it lands on (stable per CU within a process, different CUs on different boxes; clock constant at 2.39 - 2.44 GHz; every
+// instruction class alone is uniform over the CUs: tools/ubench_cu.hip), so its average is 5 - 10 % SLOWER (profiles/r04_ab/row_engine.txt).
+#ifdef BLS_ROW_SHFL
+#define BLS_ROW_GET(VV, CTRL) (((int)(threadIdx.x & 15) >= ((CTRL) & 15)) ? (uint32_t)__shfl_up((int)(VV), (CTRL) & 15, 16) : 0u)
+#else
+#define BLS_ROW_GET(VV, CTRL) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(VV), CTRL, 0xf, 0xf, true))
+#endif
+__device__ __forceinline__ void c12r_row_sum(c12r_limbs& v) {
+#define BLS_ROW_STEP(CTRL)                                                                                                        \
+    _Pragma("unroll") for (int l = 0; l < 2 * FP_N; l++) v.t[l] += BLS_ROW_GET(v.t[l], CTRL);
+    BLS_ROW_STEP(0x111)      // row_shr:1
+    BLS_ROW_STEP(0x112)      // row_shr:2
+    BLS_ROW_STEP(0x114)      // row_shr:4
+    BLS_ROW_STEP(0x118)      // row_shr:8
+#undef BLS_ROW_STEP
+}
+template <class LDS>
+__device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
+    const int t = threadIdx.x, row = (t >> 4) < 12 ? (t >> 4) : 0, q = (t >> 4) < 12 ? (t & 15) : 12;      // rows 12.. of a wider block: idle terms
+    c12r_limbs v;
+    c12r_term(S.r[a], S.r[b], row, q, v);
+    __syncthreads();
+    c12r_row_sum(v);
+    if (q == 15) {
+        fp r = c12r_reduce(v);
+        if (row & 1) S.r[d][row >> 1].c1 = r; else S.r[d][row >> 1].c0 = r;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void c12_sqr(c12_lds& S, int d, int a) { c12_mul(S, d, a, a); }
+#endif
 __device__ __forceinline__ void c12_copy(c12_lds& S, int d, int a) {
     int lane = threadIdx.x;
     if (lane < 6) S.r[d][lane] = S.r[a][lane];
@@ -813,6 +854,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
                                                        uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
     __shared__ c12_lds S;
     int lane = threadIdx.x;
+#ifdef BLS_TAIL_CLOCK
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (lane == 0) {
         S.frob[0] = fp2_one(); S.frob[1] = fp2_from_const(k::FROB_G1); S.frob[2] = fp2_from_const(k::FROB_G2);
         S.frob[3] = fp2_from_const(k::FROB_G3); S.frob[4] = fp2_from_const(k::FROB_G4); S.frob[5] = fp2_from_const(k::FROB_G5);
@@ -881,6 +925,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
             *verdict = one ? 1u : 0u;
         }
     }
+#ifdef BLS_TAIL_CLOCK
+    if ((lane & 63) == 0) {
+        uint64_t dr = __builtin_amdgcn_s_memrealtime() - rt0;
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        printf("k_tail mode %d wave %d: %.3f ms simd %u wave_slot %u cu %u se %u raw %x\n", mode, lane >> 6, (double)dr / 1e5, (hwid >> 4) & 3, hwid & 15, (hwid >> 8) & 15, (hwid >> 13) & 7, hwid);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
