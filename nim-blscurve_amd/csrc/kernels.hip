@@ -930,7 +930,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
         uint64_t dr = __builtin_amdgcn_s_memrealtime() - rt0;
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        printf("k_tail mode %d wave %d: %.3f ms simd %u wave_slot %u cu %u se %u raw %x\n", mode, lane >> 6, (double)dr / 1e5, (hwid >> 4) & 3, hwid & 15, (hwid >> 8) & 15, (hwid >> 13) & 7, hwid);
+        uint32_t ldsa;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(ldsa));
+        printf("k_tail mode %d wave %d: %.3f ms simd %u wave_slot %u cu %u se %u raw %x lds_base %u lds_size %u (granules; raw %x)\n", mode, lane >> 6, (double)dr / 1e5, (hwid >> 4) & 3, hwid & 15,
+               (hwid >> 8) & 15, (hwid >> 13) & 7, hwid, ldsa & 0xff, (ldsa >> 12) & 0x1ff, ldsa);
     }
 #endif
 }
