@@ -1,3 +1,5 @@
+# On the GPU box: k_tail / k_fold / k_hash_one durations of prebuilt variants (VARS="a b", nim-blscurve_amd/variants/<name>.so) under rocprofv3 --kernel-trace --stats,
+# plus the launch-by-launch list of k_tail durations (tests/gpu_probe_aux.py fav b4096)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so

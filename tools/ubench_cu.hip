@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(192) k(uint32_t* out, uint64_t* cyc, uint32_t*
         else if (KIND == 1) asm volatile(R16("s_nop 1\n v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n v_mov_b32_dpp %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n") : "+v"(v), "+v"(w));
         else if (KIND == 2) { R16(v = lds[(v + t) & 4095]; lds[(t * 14 + i) & 4095] = v + w;) }
         else if (KIND == 3) { R4(__syncthreads(); v += w;) }
+        else if (KIND == 5) asm volatile(R16(R16(R4("v_mad_i64_i32 %0, vcc, %1, %2, %0\n"))) : "+v"(x0) : "v"(a), "v"(b) : "vcc");      // 1024 instructions = 8 KB of straight-line code per iteration
+        else if (KIND == 6) asm volatile(R16(R16(R16("v_mad_i64_i32 %0, vcc, %1, %2, %0\n"))) : "+v"(x0) : "v"(a), "v"(b) : "vcc");     // 4096 instructions = 32 KB
         else {
             R4(v = lds[(v + t) & 4095];)
             asm volatile(R16("v_mad_i64_i32 %0, vcc, %1, %2, %0\n") : "+v"(x0) : "v"(a), "v"(b) : "vcc");
@@ -63,7 +65,30 @@ void run(const char* name, int blocks, int iters) {
     printf("\n");
     (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(hw);
 }
+// one 3-wave workgroup ALONE on the chip, launch after launch (each lands on another CU): the condition of the serial tail
+template <int KIND>
+void alone(const char* name, int iters) {
+    uint32_t* out; uint64_t* cyc; uint32_t* hw;
+    (void)hipMalloc(&out, 192 * 4); (void)hipMalloc(&cyc, 8); (void)hipMalloc(&hw, 4);
+    printf("%-34s alone:", name);
+    for (int rep = 0; rep < 24; rep++) {
+        k<KIND><<<1, 192>>>(out, cyc, hw, iters);
+        (void)hipDeviceSynchronize();
+        uint64_t c; uint32_t h;
+        (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&h, hw, 4, hipMemcpyDeviceToHost);
+        printf(" %llu(x%u.s%u.c%u)", (unsigned long long)c / 1000, (h >> 16) & 15, (h >> 13) & 7, (h >> 8) & 15);
+    }
+    printf("\n");
+    (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(hw);
+}
 int main() {
+    alone<0>("v_mad_i64_i32 dependent", 4000);
+    alone<1>("v_mov_b32_dpp row_shr", 4000);
+    alone<2>("LDS read + write", 2000);
+    alone<3>("s_barrier rounds (3 waves)", 4000);
+    alone<4>("row-engine-shaped mix", 2000);
+    alone<5>("8 KB straight-line mad loop", 200);
+    alone<6>("32 KB straight-line mad loop", 50);
     for (int blocks : {256, 32}) {
         run<0>("v_mad_i64_i32 dependent", blocks, 4000);
         run<1>("v_mov_b32_dpp row_shr", blocks, 4000);
