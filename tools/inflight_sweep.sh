@@ -1,0 +1,9 @@
+# On the GPU box: pipelined step time against the number of batches in flight and the chaining event, two passes
+cd $GRAFT_REPO_ROOT
+for pass in 1 2; do
+for cfg in "3 -" "2 -" "4 -" "3 hm" "3 clear" "3 sig" "3 lines"; do
+  set -- $cfg
+  echo -n "inflight=$1 chain_ev=$2  "
+  if [ "$2" = "-" ]; then python3 bench.py --steps 30 --warmup 4 --no-cpu --no-aux --no-one-caller --inflight $1 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.readline())['ms_per_step'],3))"
+  else MI355_BLS_CHAIN_EV=$2 python3 bench.py --steps 30 --warmup 4 --no-cpu --no-aux --no-one-caller --inflight $1 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.readline())['ms_per_step'],3))"; fi
+done; done
