@@ -17,6 +17,9 @@ struct c12_work {
     fp prod[108];               // Karatsuba triples (t0, t1, s) of the 36 (or 21) coefficient pairs
     int32_t lo[12][FP_N];       // phase 2a: low 28 bits of every combined limb (top limb: the whole signed value)
     int32_t car[12][FP_N];      // phase 2a: carry into limb l (from limb l - 1)
+#ifdef BLS_TAIL_CLOCK
+    unsigned long long prof[8]; // diagnostic build: time of thread 0 in each phase of the engine product
+#endif
 };
 
 BLS_HD int c12_flat_of_tower(int t) { return t < 3 ? 2 * t : 2 * (t - 3) + 1; }
@@ -34,11 +37,9 @@ BLS_HD fp c12_triple(const fp2& x, const fp2& y, int kind) {
 // phase 1, item q (q < 108: product of A and B; sqr: q < 63, B == A)
 BLS_HD fp c12_phase1(const fp2* A, const fp2* B, int q, bool sqr) {
     int pr = q / 3, kind = q % 3, i, j;
-    if (sqr) {
-        int base = 0;
-        i = 0;
-        while (pr >= base + (6 - i)) { base += 6 - i; i++; }
-        j = i + (pr - base);
+    if (sqr) {                      // row-by-row enumeration of the pairs i <= j (rows start at 0, 6, 11, 15, 18, 20), without a search loop
+        i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
+        j = i + pr - (i * 6 - (i * (i - 1)) / 2);
     } else {
         i = pr / 6;
         j = pr % 6;
@@ -52,23 +53,32 @@ BLS_HD fp c12_phase1(const fp2* A, const fp2* B, int q, bool sqr) {
 //   wrapped: re - im = 2 t0 - s  re + im = s - 2 t1
 // Products have limbs 0..12 in [0, 2^28) and a small signed top limb, so the sum of at most 6 * 2 * 4 of them is exact in 64 bits.
 BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
-    int c = t / FP_N, l = t % FP_N, kk = c >> 1, comp = c & 1;
+    const int c = t / FP_N, l = t % FP_N, kk = c >> 1, comp = c & 1;
     int64_t s = 0;
-    for (int i = 0; i < 6; i++) {
+    // Six terms, no branches (round 4: the loop with its skipped and doubled terms cost 1 840 cycles per product on the critical thread, a quarter of
+    // the engine's time; this form ~700): a square's unordered pair {i, j}, i != j, is met twice - as (i, j) and as (j, i), the same stored triple -
+    // which IS the factor two; the coefficients of (t0, t1, s) depend on the component and on whether the term wraps around w^6 = xi.
+    int32_t v0[6], v1[6], v2[6], c0[6], c1[6], cs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {                       // all 18 limbs first (one LDS round trip, not six), then the multiply-adds
         int j = kk - i;
-        bool wrap = j < 0;
-        if (wrap) j += 6;
-        int mult = 1, pr = i * 6 + j;
-        if (sqr) {
-            if (i > j) continue;                              // (j, i) is counted, doubled
-            pr = c12_sqr_pair_index(i, j);
-            mult = i == j ? 1 : 2;
-        }
-        int c0 = comp ? (wrap ? 0 : -1) : (wrap ? 2 : 1);
-        int c1 = comp ? (wrap ? -2 : -1) : (wrap ? 0 : -1);
-        int cs = comp ? 1 : (wrap ? -1 : 0);
+        const bool wrap = j < 0;
+        j += wrap ? 6 : 0;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        const int pr = sqr ? c12_sqr_pair_index(a, b) : i * 6 + j;
+        c0[i] = comp ? (wrap ? 0 : -1) : (wrap ? 2 : 1);
+        c1[i] = comp ? (wrap ? -2 : -1) : (wrap ? 0 : -1);
+        cs[i] = comp ? 1 : (wrap ? -1 : 0);
         const fp* t3 = &W.prod[3 * pr];
-        s += (int64_t)mult * (c0 * (int64_t)(int32_t)t3[0].l[l] + c1 * (int64_t)(int32_t)t3[1].l[l] + cs * (int64_t)(int32_t)t3[2].l[l]);
+        v0[i] = (int32_t)t3[0].l[l];
+        v1[i] = (int32_t)t3[1].l[l];
+        v2[i] = (int32_t)t3[2].l[l];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        s = bls_mac(s, c0[i], v0[i]);
+        s = bls_mac(s, c1[i], v1[i]);
+        s = bls_mac(s, cs[i], v2[i]);
     }
     if (l < FP_N - 1) {
         W.lo[c][l] = (int32_t)(s & (int64_t)FP_MASK);

@@ -639,7 +639,7 @@ constexpr int C12_NREG = 8;
 #ifdef BLS_C12_ROW
 constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 192;          // the row engine: 12 rows of 16 lanes
 #else
-constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 128;          // both >= 108: phase 1 is one product per thread
+constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 192;          // >= 168: one limb item per thread in phase 2a (and >= 108 products in phase 1)
 #endif          // the row engine: 12 rows of 16 lanes (the Karatsuba engine needed >= 108)
 struct c12_lds {
     fp2 r[C12_NREG][6];
@@ -649,33 +649,78 @@ struct c12_lds {
     uint32_t steps[N_LINES * 6 * 2 * FP_N];     // the 68 step products, flat basis (46 KB): loaded once, no global load per Horner step
 };
 
+#ifdef BLS_TAIL_CLOCK
+#define C12_T0 unsigned long long last_ = __builtin_amdgcn_s_memtime()
+#define C12_STAMP(i) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) S.w.prof[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define C12_T0 do { } while (0)
+#define C12_STAMP(i) do { } while (0)
+#endif
 #ifndef BLS_C12_ROW
+// Phase 1 with the KIND of the Karatsuba triple uniform per wave (wave 0: x.c0 y.c0, wave 1: x.c1 y.c1, wave 2: the sums), pair index = lane within
+// the wave: the operand selection is a scalar branch instead of two selects per limb and operand, and only the third wave loads both halves and adds
+// (the lane-per-product enumeration of c12_phase1, which the host harness keeps, had the three kinds in neighbouring lanes: 310 instructions of
+// operand preparation in front of a 700-instruction multiplication).  Blocks of exactly three waves.
+template <int NPAIRS, bool SQR, class LDS>
+__device__ __forceinline__ void c12_products(LDS& S, int a, int b) {
+    const int kind = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pr = (int)(threadIdx.x & 63);
+    if (pr < NPAIRS) {
+        int i, j;
+        if (SQR) {
+            i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
+            j = i + pr - (i * 6 - (i * (i - 1)) / 2);
+        } else {
+            i = pr / 6;
+            j = pr % 6;
+        }
+        const fp2 &x = S.r[a][i], &y = S.r[b][j];
+        fp u, v;
+        if (kind == 0) { u = x.c0; v = y.c0; }
+        else if (kind == 1) { u = x.c1; v = y.c1; }
+        else { u = fp_add_nc(x.c0, x.c1); v = fp_add_nc(y.c0, y.c1); }
+        S.w.prod[3 * pr + kind] = fp_mul(u, v);
+    }
+}
 // d = a * b (flat basis); d may be a or b.  LDS: any block-shared struct with the registers r[][6] and the work area w.
 template <class LDS>
 __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
     int lane = threadIdx.x;
-    if (lane < 108) S.w.prod[lane] = c12_phase1(S.r[a], S.r[b], lane, false);
+    C12_T0;
+    c12_products<36, false>(S, a, b);
+    C12_STAMP(0);
     __syncthreads();
-    for (int t = lane; t < 12 * FP_N; t += (int)blockDim.x) c12_phase2a(S.w, t, false);
+    C12_STAMP(1);
+    if (lane < 12 * FP_N) c12_phase2a(S.w, lane, false);          // blocks of TAIL_THREADS = 192 >= 168 threads: no loop
+    C12_STAMP(2);
     __syncthreads();
+    C12_STAMP(3);
     if (lane < 12) {
         fp v = c12_phase2b(S.w, lane);
         if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
     }
+    C12_STAMP(4);
     __syncthreads();
+    C12_STAMP(5);
 }
 // d = a^2: only the 21 pairs i <= j are formed, 63 Fp products
 __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
     int lane = threadIdx.x;
-    if (lane < 63) S.w.prod[lane] = c12_phase1(S.r[a], S.r[a], lane, true);
+    C12_T0;
+    c12_products<21, true>(S, a, a);
+    C12_STAMP(0);
     __syncthreads();
-    for (int t = lane; t < 12 * FP_N; t += (int)blockDim.x) c12_phase2a(S.w, t, true);
+    C12_STAMP(1);
+    if (lane < 12 * FP_N) c12_phase2a(S.w, lane, true);
+    C12_STAMP(2);
     __syncthreads();
+    C12_STAMP(3);
     if (lane < 12) {
         fp v = c12_phase2b(S.w, lane);
         if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
     }
+    C12_STAMP(4);
     __syncthreads();
+    C12_STAMP(5);
 }
 #else
 // Row engine (c12.hpp, c12r_*; -DBLS_C12_ROW): thread (row = t / 16, q = t % 16) of the 192; d may be a or b (every operand is read before the first
@@ -856,6 +901,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
     int lane = threadIdx.x;
 #ifdef BLS_TAIL_CLOCK
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x < 8) S.w.prof[threadIdx.x] = 0;
 #endif
     if (lane == 0) {
         S.frob[0] = fp2_one(); S.frob[1] = fp2_from_const(k::FROB_G1); S.frob[2] = fp2_from_const(k::FROB_G2);
@@ -932,6 +978,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         uint32_t ldsa;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(ldsa));
+#ifndef BLS_C12_ROW
+        if (lane == 0) printf("   engine phases, ticks of thread 0 (whole kernel %llu): products %llu  barrier %llu  limb sums %llu  barrier %llu  reductions %llu  barrier %llu\n",
+                              (unsigned long long)(__builtin_amdgcn_s_memtime() - clk0), S.w.prof[0], S.w.prof[1], S.w.prof[2], S.w.prof[3], S.w.prof[4], S.w.prof[5]);
+#endif
         printf("k_tail mode %d wave %d: %.3f ms simd %u wave_slot %u cu %u se %u raw %x lds_base %u lds_size %u (granules; raw %x)\n", mode, lane >> 6, (double)dr / 1e5, (hwid >> 4) & 3, hwid & 15,
                (hwid >> 8) & 15, (hwid >> 13) & 7, hwid, ldsa & 0xff, (ldsa >> 12) & 0x1ff, ldsa);
     }
