@@ -52,12 +52,13 @@ BLS_HD fp c12_phase1(const fp2* A, const fp2* B, int q, bool sqr) {
 //   plain:   re = t0 - t1        im = s - t0 - t1
 //   wrapped: re - im = 2 t0 - s  re + im = s - 2 t1
 // Products have limbs 0..12 in [0, 2^28) and a small signed top limb, so the sum of at most 6 * 2 * 4 of them is exact in 64 bits.
-BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
-    const int c = t / FP_N, l = t % FP_N, kk = c >> 1, comp = c & 1;
+// the signed 64-bit sum of limb l of coefficient c (kk = c / 2 the power of w, comp = c % 2 real / imaginary) over the six terms
+BLS_HD int64_t c12_limb_sum(const c12_work& W, int c, int l, bool sqr) {
+    const int kk = c >> 1, comp = c & 1;
     int64_t s = 0;
-    // Six terms, no branches (round 4: the loop with its skipped and doubled terms cost 1 840 cycles per product on the critical thread, a quarter of
-    // the engine's time; this form ~700): a square's unordered pair {i, j}, i != j, is met twice - as (i, j) and as (j, i), the same stored triple -
-    // which IS the factor two; the coefficients of (t0, t1, s) depend on the component and on whether the term wraps around w^6 = xi.
+    // Six terms, no branches (round 4: the loop with its skipped and doubled terms and one LDS round trip per term cost 1 840 cycles per product on the
+    // critical thread, a quarter of the engine's time): a square's unordered pair {i, j}, i != j, is met twice - as (i, j) and as (j, i), the same stored
+    // triple - which IS the factor two; the coefficients of (t0, t1, s) depend on the component and on whether the term wraps around w^6 = xi.
     int32_t v0[6], v1[6], v2[6], c0[6], c1[6], cs[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {                       // all 18 limbs first (one LDS round trip, not six), then the multiply-adds
@@ -80,6 +81,11 @@ BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
         s = bls_mac(s, c1[i], v1[i]);
         s = bls_mac(s, cs[i], v2[i]);
     }
+    return s;
+}
+BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
+    const int c = t / FP_N, l = t % FP_N;
+    const int64_t s = c12_limb_sum(W, c, l, sqr);
     if (l < FP_N - 1) {
         W.lo[c][l] = (int32_t)(s & (int64_t)FP_MASK);
         W.car[c][l + 1] = (int32_t)(s >> 28);
@@ -87,6 +93,43 @@ BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
         W.lo[c][l] = (int32_t)s;
     }
     if (l == 0) W.car[c][0] = 0;
+}
+
+// ---- Phase 2 on rows (round 4): lane (c, l) = (t / 16, t % 16) of a 192-thread block keeps ITS limb in a register from the sum to the stored result;
+// the two carry steps and the partial reduction of phases 2a / 2b (twelve lanes walking fourteen limbs each, behind a barrier) become per-lane
+// arithmetic with the neighbour's carry (a DPP row shift on the device, an array in the host harness) and the quotient of lane 13.
+// Pieces, each a pure function of one lane's values:
+//   c12_split(s, l)          -> low 28 bits and carry of a signed 64-bit limb value (the top limb l = 13 keeps everything)
+//   c12_quotient(top)        -> round(v / p) from the top limb + the carry-in it will receive, as fp_reduce does
+//   c12_sub_qp(limb, q, l)   -> limb - q * p_l (64 bits)
+// Result limbs lie in (-2^7, 2^28 + 2^7): semi-normalised (limb bound 1), |value| < 0.51 p like fp_reduce's.
+struct c12_lc { int32_t lo, car; };
+BLS_HD c12_lc c12_split(int64_t s, int l) {
+    c12_lc r;
+    if (l < FP_N - 1) { r.lo = (int32_t)(s & (int64_t)FP_MASK); r.car = (int32_t)(s >> 28); }
+    else { r.lo = (int32_t)s; r.car = 0; }
+    return r;
+}
+BLS_HD int32_t c12_quotient(int32_t top) {
+    const int64_t RECIP = 10322735;                       // round(2^40 / (p / 2^364)), as in fp_reduce
+    return (int32_t)(((int64_t)top * RECIP + (1ll << 39)) >> 40);
+}
+BLS_HD int32_t c12_p_limb(int l) {                      // limb l of p, by selection (l differs per lane)
+    int32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) v = l == i ? (int32_t)k::P[i] : v;
+    return v;
+}
+BLS_HD int64_t c12_sub_qp(int32_t limb, int32_t q, int l) { return (int64_t)limb - (int64_t)q * c12_p_limb(l); }
+// the whole row step on arrays (host harness; the device composes the same pieces with DPP): s[16] -> out limbs [14]
+BLS_HD void c12_row_reduce_ref(const int64_t (&s)[16], int32_t (&out)[FP_N]) {
+    int32_t limb[16], car[16];
+    for (int l = 0; l < 16; l++) { c12_lc x = c12_split(l < FP_N ? s[l] : 0, l < FP_N ? l : 0); limb[l] = x.lo; car[l] = l < FP_N ? x.car : 0; }
+    for (int l = FP_N - 1; l > 0; l--) limb[l] += car[l - 1];
+    const int32_t q = c12_quotient(limb[FP_N - 1] + (limb[FP_N - 2] >> 28));
+    int32_t lo2[16], car2[16];
+    for (int l = 0; l < FP_N; l++) { c12_lc x = c12_split(c12_sub_qp(limb[l], q, l), l); lo2[l] = x.lo; car2[l] = x.car; }
+    for (int l = 0; l < FP_N; l++) out[l] = lo2[l] + (l ? car2[l - 1] : 0);
 }
 
 // phase 2b, coefficient c < 12: the value (|v| <= 36 p: six terms of at most three products of |v| < 2p each, doubled at most)

@@ -682,45 +682,51 @@ __device__ __forceinline__ void c12_products(LDS& S, int a, int b) {
     }
 }
 // d = a * b (flat basis); d may be a or b.  LDS: any block-shared struct with the registers r[][6] and the work area w.
+// Phase 2 on rows (c12.hpp): thread (c, l) = (t / 16, t % 16) keeps its limb in a register from the 18-term sum to the stored result; carries travel by
+// DPP row shifts, the quotient of the partial reduction comes from lane 13 of the row (v_readlane per row of the wave).  One barrier less per product and
+// ~60 instructions on every lane instead of ~280 on twelve.
+__device__ __forceinline__ int32_t c12_shr1(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }      // lane l <- lane l - 1 of its 16-lane row, 0 into lane 0
+template <bool SQR, class LDS>
+__device__ __forceinline__ void c12_phase2_rows(LDS& S, int d) {
+    const int t = threadIdx.x, c = t >> 4, l = t & 15;
+    const bool live = l < FP_N;
+    const int ll = live ? l : 0;
+    const c12_lc x = c12_split(c12_limb_sum(S.w, c, ll, SQR), ll);
+    const int32_t limb = x.lo + c12_shr1(live ? x.car : 0);
+    const int32_t qv = c12_quotient(limb + c12_shr1(limb >> 28));          // right in lane 13 of the row
+    const int32_t q0 = __builtin_amdgcn_readlane(qv, 13), q1 = __builtin_amdgcn_readlane(qv, 29), q2 = __builtin_amdgcn_readlane(qv, 45), q3 = __builtin_amdgcn_readlane(qv, 61);
+    const int r = (t >> 4) & 3;
+    const int32_t q = r == 0 ? q0 : (r == 1 ? q1 : (r == 2 ? q2 : q3));
+    const c12_lc y = c12_split(c12_sub_qp(limb, q, ll), ll);
+    const int32_t out = y.lo + c12_shr1(live ? y.car : 0);
+    if (live) {
+        fp2& dst = S.r[d][c >> 1];
+        ((c & 1) ? dst.c1 : dst.c0).l[l] = (uint32_t)out;
+    }
+}
 template <class LDS>
 __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
-    int lane = threadIdx.x;
     C12_T0;
     c12_products<36, false>(S, a, b);
     C12_STAMP(0);
     __syncthreads();
     C12_STAMP(1);
-    if (lane < 12 * FP_N) c12_phase2a(S.w, lane, false);          // blocks of TAIL_THREADS = 192 >= 168 threads: no loop
+    c12_phase2_rows<false>(S, d);
     C12_STAMP(2);
     __syncthreads();
     C12_STAMP(3);
-    if (lane < 12) {
-        fp v = c12_phase2b(S.w, lane);
-        if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
-    }
-    C12_STAMP(4);
-    __syncthreads();
-    C12_STAMP(5);
 }
 // d = a^2: only the 21 pairs i <= j are formed, 63 Fp products
 __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
-    int lane = threadIdx.x;
     C12_T0;
     c12_products<21, true>(S, a, a);
     C12_STAMP(0);
     __syncthreads();
     C12_STAMP(1);
-    if (lane < 12 * FP_N) c12_phase2a(S.w, lane, true);
+    c12_phase2_rows<true>(S, d);
     C12_STAMP(2);
     __syncthreads();
     C12_STAMP(3);
-    if (lane < 12) {
-        fp v = c12_phase2b(S.w, lane);
-        if (lane & 1) S.r[d][lane >> 1].c1 = v; else S.r[d][lane >> 1].c0 = v;
-    }
-    C12_STAMP(4);
-    __syncthreads();
-    C12_STAMP(5);
 }
 #else
 // Row engine (c12.hpp, c12r_*; -DBLS_C12_ROW): thread (row = t / 16, q = t % 16) of the 192; d may be a or b (every operand is read before the first
@@ -979,8 +985,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
         uint32_t ldsa;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(ldsa));
 #ifndef BLS_C12_ROW
-        if (lane == 0) printf("   engine phases, ticks of thread 0 (whole kernel %llu): products %llu  barrier %llu  limb sums %llu  barrier %llu  reductions %llu  barrier %llu\n",
-                              (unsigned long long)(__builtin_amdgcn_s_memtime() - clk0), S.w.prof[0], S.w.prof[1], S.w.prof[2], S.w.prof[3], S.w.prof[4], S.w.prof[5]);
+        if (lane == 0) printf("   engine phases, ticks of thread 0 (whole kernel %llu): products %llu  barrier %llu  limb sums + reduction %llu  barrier %llu\n",
+                              (unsigned long long)(__builtin_amdgcn_s_memtime() - clk0), S.w.prof[0], S.w.prof[1], S.w.prof[2], S.w.prof[3]);
 #endif
         printf("k_tail mode %d wave %d: %.3f ms simd %u wave_slot %u cu %u se %u raw %x lds_base %u lds_size %u (granules; raw %x)\n", mode, lane >> 6, (double)dr / 1e5, (hwid >> 4) & 3, hwid & 15,
                (hwid >> 8) & 15, (hwid >> 13) & 7, hwid, ldsa & 0xff, (ldsa >> 12) & 0x1ff, ldsa);
