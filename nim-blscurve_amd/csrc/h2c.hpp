@@ -26,7 +26,7 @@ BLS_HDN void hash_to_field_fp2x2(fp2& u0, fp2& u1, const uint8_t* msg, uint32_t 
     sha256_ctx c;
     uint32_t b0[8], bi[8];
     sha256_begin(c);
-    for (int i = 0; i < 64; i++) sha256_put(c, 0);     // Z_pad
+    sha256_zero_block(c);                               // Z_pad
     sha256_update(c, msg, msg_len);
     sha256_put(c, 0x01);                                // l_i_b_str = 256
     sha256_put(c, 0x00);

@@ -102,8 +102,23 @@ BLS_HD void sha256_update(sha256_ctx& c, const uint8_t* p, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) sha256_put(c, p[i]);
 }
 
+// absorb one block of 64 zero bytes into an EMPTY buffer (Z_pad of expand_message_xmd): one compression, no byte-wise buffering
+BLS_HD void sha256_zero_block(sha256_ctx& c) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) c.w[i] = 0;
+    sha256_compress(c.h, c.w);
+    c.total += 64;
+}
+
 // absorb a digest given as 8 big-endian words
 BLS_HD void sha256_update_words(sha256_ctx& c, const uint32_t (&d)[8]) {
+    if (c.fill == 0) {                                  // word-aligned (every use in expand_message_xmd): the words go in whole
+#pragma unroll
+        for (int i = 0; i < 8; i++) c.w[i] = d[i];
+        c.fill = 32;
+        c.total += 32;
+        return;
+    }
     for (int i = 0; i < 8; i++) {
         sha256_put(c, (uint8_t)(d[i] >> 24));
         sha256_put(c, (uint8_t)(d[i] >> 16));
