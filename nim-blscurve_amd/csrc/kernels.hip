@@ -364,6 +364,69 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
 // reductions as curve.hpp's): roles 0..2 take the three independent products of each of the first two rounds
 // device teams: lanes gbase .. gbase + 7 hold the same values; roles 0.. take one product each of a round (ONE multiplier call
 // with per-lane operands), then every lane reads all results with wave shuffles.  Formulas: jac_dbl_team / miller_dbl_step_team.
+template <int CTRL>
+__device__ __forceinline__ fp fp_quad_perm(const fp& a) {
+    fp r;
+#ifdef BLS_TEAM_SHFL
+    const int q = threadIdx.x & 3, src = (threadIdx.x & ~3) | ((CTRL >> (2 * q)) & 3);
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
+#else
+#pragma unroll
+    for (int i = 0; i < FP_N; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], CTRL, 0xf, 0xf, true);
+#endif
+    return r;
+}
+// The same interface on SIXTEEN lanes (one DPP row) for the one-message kernel, whose whole wave serves one point: an Fp2 product is FOUR Fp products on four
+// lanes (role r: product r / 4, part r % 4 = a0 b0 | a1 b1 | a0 b1 | a1 b0), combined inside the quad with one DPP exchange (real = p0 - p1, imaginary = p2 + p3)
+// and partially reduced, so a round costs a 392-multiply-add Fp product instead of the 784 of a lazily reduced half (k_hash_one's mul rounds 4.6 k -> ~3 k cycles).
+// Squares are two Fp products already and keep the two-lanes-per-square form.  Results: |value| < 0.51 p, carried limbs - tighter than team_lanes8's.
+struct team_lanes16 {
+    uint32_t gbase, role;
+    __device__ __forceinline__ fp quarter(const fp2& a, const fp2& b) const {
+        const uint32_t part = role & 3;
+        const bool second = part == 1;
+        fp v = fp_mul(fp_select((part & 1) != 0, a.c1, a.c0), fp_select(part == 1 || part == 2, b.c1, b.c0));
+        fp w = fp_quad_perm<0xb1>(v);                                      // the partner's product: parts 0 <-> 1, 2 <-> 3
+        fp d = fp_sub_nc(fp_select(second, w, v), fp_select(second, v, w));  // p0 - p1 in both lanes of the first pair
+        return fp_reduce(fp_select(part >= 2, fp_add_nc(v, w), d));
+    }
+    __device__ __forceinline__ fp2 gatherq(const fp& v, uint32_t q) const { return fp2{fp_from_role(v, gbase, 4 * q), fp_from_role(v, gbase, 4 * q + 2)}; }
+    __device__ __forceinline__ fp2 pick4(const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3) const {
+        const uint32_t q = role >> 2;
+        return fp2_select(q < 2, fp2_select(q == 0, a0, a1), fp2_select(q == 2, a2, a3));
+    }
+    __device__ __forceinline__ void mul4(fp2& r0, fp2& r1, fp2& r2, fp2& r3, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2,
+                                         const fp2& a3, const fp2& b3) const {
+        fp v = quarter(pick4(a0, a1, a2, a3), pick4(b0, b1, b2, b3));
+        r0 = gatherq(v, 0); r1 = gatherq(v, 1); r2 = gatherq(v, 2); r3 = gatherq(v, 3);
+    }
+    __device__ __forceinline__ void mul3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2) const {
+        fp v = quarter(pick4(a0, a1, a2, a2), pick4(b0, b1, b2, b2));
+        r0 = gatherq(v, 0); r1 = gatherq(v, 1); r2 = gatherq(v, 2);
+    }
+    __device__ __forceinline__ void mul2(fp2& r0, fp2& r1, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1) const {
+        const bool first = (role >> 2) == 0;
+        fp v = quarter(fp2_select(first, a0, a1), fp2_select(first, b0, b1));
+        r0 = gatherq(v, 0); r1 = gatherq(v, 1);
+    }
+    __device__ __forceinline__ fp2 mul1(const fp2& a, const fp2& b) const { return gatherq(quarter(a, b), 0); }
+    // squares: role r < 6 takes half r % 2 of square r / 2, as in team_lanes8
+    __device__ __forceinline__ fp half_sqr(const fp2& a) const {
+        const bool im = (role & 1) != 0;
+        return fp_mul(fp_select(im, fp_dbl_nc(a.c0), fp_add_nc(a.c0, a.c1)), fp_select(im, a.c1, fp_sub_nc(a.c0, a.c1)));
+    }
+    __device__ __forceinline__ fp2 gather2(const fp& v, uint32_t q) const { return fp2{fp_from_role(v, gbase, 2 * q), fp_from_role(v, gbase, 2 * q + 1)}; }
+    __device__ __forceinline__ void sqr3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& a1, const fp2& a2) const {
+        const uint32_t q = role >> 1;
+        fp v = half_sqr(fp2_select(q == 0, a0, fp2_select(q == 1, a1, a2)));
+        r0 = gather2(v, 0); r1 = gather2(v, 1); r2 = gather2(v, 2);
+    }
+    __device__ __forceinline__ void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const {
+        fp v = half_sqr(fp2_select((role >> 1) == 0, a0, a1));
+        r0 = gather2(v, 0); r1 = gather2(v, 1);
+    }
+};
 struct team_lanes8 {
     uint32_t gbase, role;
     // An Fp2 product is two independent dot products, an Fp2 square two independent Fp products: SIX lanes take one HALF each
@@ -423,17 +486,18 @@ struct team_lanes8 {
 __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return jac_dbl_team(p, team_lanes8{gbase, role}); }
 // clear_cofactor_g2 (h2c.hpp) with the two 63-doubling chains lane-parallel; the chain accumulator stays in registers (inlined
 // loop), the base point waits in the registers of the team (every lane holds it anyway)
-__device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) {
+template <class Team>
+__device__ __forceinline__ g2_jac clear_cofactor_g2_team(const g2_jac& p, const Team& team) {
 #if defined(BLS_COOP_PARK_LDS) && defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 coop_park_slots[3 * BLS_LDS_SLOT];
     g2_park_lds park{(bls_lds_u32x4*)coop_park_slots};
 #else
     g2_park_regs park;
 #endif
-    team_lanes8 team{gbase, role};
     auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
     return clear_cofactor_g2_bits(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
 }
+__device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return clear_cofactor_g2_team(p, team_lanes8{gbase, role}); }
 __device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
@@ -466,11 +530,12 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
 #ifdef BLS_TAIL_CLOCK
     ts[3] = __builtin_amdgcn_s_memtime();
 #endif
-    g2_jac sum = g2_add_coop(q0, q1, gbase, role);
+    const team_lanes16 team{threadIdx.x & ~15u, threadIdx.x & 15u};      // the addition and the cofactor chain on quarter products (16 lanes per team)
+    g2_jac sum = jac_add_team(q0, q1, team);
 #ifdef BLS_TAIL_CLOCK
     ts[4] = __builtin_amdgcn_s_memtime();
 #endif
-    g2_jac h = clear_cofactor_g2_coop(sum, gbase, role);
+    g2_jac h = clear_cofactor_g2_team(sum, team);
 #ifdef BLS_TAIL_CLOCK
     ts[5] = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) printf("k_hash_one ticks: hash_to_field %llu  sswu %llu  isogeny+gather %llu  add %llu  cofactor %llu\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
@@ -1436,19 +1501,6 @@ __global__ void __launch_bounds__(WAVE) k_pip_segred(const uint4* __restrict__ b
 // G1 lane teams for the latency-bound reductions: T = 2 or 4 ADJACENT lanes hold the same values; product k of a round runs in lane k mod T
 // (round k / T) and the results are shared with DPP quad permutes (no LDS, no ds_bpermute).  A Jacobian addition costs 5 (T = 4) or 8
 // (T = 2) multiplication times instead of 16, a doubling 3 or 5 instead of 7.  The formulas are jac_add_team / jac_dbl_team (curve.hpp).
-template <int CTRL>
-__device__ __forceinline__ fp fp_quad_perm(const fp& a) {
-    fp r;
-#ifdef BLS_TEAM_SHFL
-    const int q = threadIdx.x & 3, src = (threadIdx.x & ~3) | ((CTRL >> (2 * q)) & 3);
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) r.l[i] = __shfl(a.l[i], src, WAVE);
-#else
-#pragma unroll
-    for (int i = 0; i < FP_N; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], CTRL, 0xf, 0xf, true);
-#endif
-    return r;
-}
 template <int T>
 struct team_quad_fp {
     uint32_t h;                       // threadIdx.x & (T - 1)
