@@ -542,14 +542,22 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
 #endif
     if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, h);
 }
-// batch form for batches that would not fill the chip with one lane per message: 8 lanes per message
+// batch form for batches that would not fill the chip with one lane per message: 8 lanes per message, or 16 (quarter products, team_lanes16) while
+// 16 lanes per message still fit the chip's one-per-SIMD wave slots (<= 4 096 messages)
+template <int L>
 __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
-    const uint32_t role = threadIdx.x & 7u, gbase = threadIdx.x & ~7u;
-    uint32_t i = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const uint32_t role = threadIdx.x & (L - 1), gbase = threadIdx.x & ~(uint32_t)(L - 1);
+    uint32_t i = blockIdx.x * (WAVE / L) + (threadIdx.x / L);
     bool live = i < n;
     if (!live) i = 0;
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
-    g2_jac h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
+    g2_jac h;
+    if (L == 16) {
+        const team_lanes16 team{gbase, role};
+        h = clear_cofactor_g2_team(jac_add_team(q0, q1, team), team);
+    } else {
+        h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
+    }
     if (live && role == 0) soa_st_g2(H, stride, i, h);
 }
 
@@ -2350,8 +2358,10 @@ static int run_pairs(mi355_bls_ctx* c, const uint8_t* d_sets, size_t n, hipStrea
     // ---- hashing (caller's stream)
     k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(d_sets, n32, c->dst, c->xmd, c->d_M, c->mstride);
     HIPCHK(hipEventRecord(c->ev_hm, st));
-    if (c->coop && (n32 + 7) / 8 <= c->slots)
-        k_hash_clear_coop<<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+    if (c->coop && (n32 + 3) / 4 <= c->slots / 2)            // 16 lanes per message while that leaves half the wave slots free (at 4 096 messages it fills the chip and gains nothing)
+        k_hash_clear_coop<16><<<(n32 + 3) / 4, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+    else if (c->coop && (n32 + 7) / 8 <= c->slots)
+        k_hash_clear_coop<8><<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     else
         k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     HIPCHK(hipEventRecord(c->ev[2], st));
@@ -3870,8 +3880,10 @@ static int aggv_slice(mi355_bls_ctx* c, const uint8_t* pks, const uint8_t* msgs,
         // side of the staging buffer (keys | offsets | messages are packed at its start; the records go to d_comp)
         k_aggv_records<<<nb, WAVE, 0, st>>>(d_msgs, n32, c->d_comp);
         k_hash_map<<<(2 * n32 + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_comp, n32, c->dst, c->xmd, c->d_M, c->mstride);
-        if (c->coop && (n32 + 7) / 8 <= c->slots)
-            k_hash_clear_coop<<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+        if (c->coop && (n32 + 3) / 4 <= c->slots / 2)            // 16 lanes per message while that leaves half the wave slots free (at 4 096 messages it fills the chip and gains nothing)
+            k_hash_clear_coop<16><<<(n32 + 3) / 4, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
+        else if (c->coop && (n32 + 7) / 8 <= c->slots)
+            k_hash_clear_coop<8><<<(n32 + 7) / 8, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
         else
             k_hash_clear<<<nb, WAVE, 0, st>>>(c->d_M, c->mstride, n32, c->d_H, c->stride);
     } else {
