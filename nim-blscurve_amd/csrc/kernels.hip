@@ -426,6 +426,19 @@ struct team_lanes16 {
         fp v = half_sqr(fp2_select((role >> 1) == 0, a0, a1));
         r0 = gather2(v, 0); r1 = gather2(v, 1);
     }
+    // five squares = ten halves on ten lanes: ONE Fp product time (team_lanes8: a whole Fp2 square, two products, on each of five lanes)
+    __device__ __forceinline__ void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
+        const uint32_t q = role >> 1;
+        fp v = half_sqr(fp2_select(q == 0, a0, fp2_select(q == 1, a1, fp2_select(q == 2, a2, fp2_select(q == 3, a3, a4)))));
+        r0 = gather2(v, 0); r1 = gather2(v, 1); r2 = gather2(v, 2); r3 = gather2(v, 3); r4 = gather2(v, 4);
+    }
+    __device__ __forceinline__ void fpmul6(fp (&r)[6], const fp (&a)[6], const fp (&b)[3]) const {
+        fp xa = fp_select(role == 0, a[0], fp_select(role == 1, a[1], fp_select(role == 2, a[2], fp_select(role == 3, a[3], fp_select(role == 4, a[4], a[5])))));
+        fp xb = fp_select(role < 2, b[0], fp_select(role < 4, b[1], b[2]));
+        fp v = fp_mul(xa, xb);
+#pragma unroll
+        for (int i = 0; i < 6; i++) r[i] = fp_from_role(v, gbase, (uint32_t)i);
+    }
 };
 struct team_lanes8 {
     uint32_t gbase, role;
@@ -581,13 +594,15 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
 // times per step instead of 15.  Same formulas, carries and reductions as miller_dbl_step; the 5 addition steps likewise
 // (miller_add_step_team: six rounds).  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.8 ms).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ line_t miller_dbl_step_coop(g2_proj& t, const g1_pre& p, uint32_t gbase, uint32_t role) {
-    return miller_dbl_step_team(t, p, team_lanes8{gbase, role});
-}
+template <int L> struct team_of { typedef team_lanes8 type; };
+template <> struct team_of<16> { typedef team_lanes16 type; };
+// L = 8 lanes per pair, or 16 (team_lanes16: quarter products, ten half squares in one round) while the pairs leave half the chip's wave slots free
+template <int L>
 __global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
                                                      uint4* __restrict__ lines) {
-    const uint32_t role = threadIdx.x & 7u, gbase = threadIdx.x & ~7u;
-    uint32_t i = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const uint32_t role = threadIdx.x & (L - 1), gbase = threadIdx.x & ~(uint32_t)(L - 1);
+    const typename team_of<L>::type team{gbase, role};
+    uint32_t i = blockIdx.x * (WAVE / L) + (threadIdx.x / L);
     bool live = i < count;
     i = first + (live ? i : 0);                                  // idle groups recompute pair `first` (no stores)
     g1_jac pj = soa_ld_g1(P, stride, i);
@@ -610,8 +625,8 @@ __global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P
     };
 #pragma clang loop unroll(disable)
     for (int bit = 62; bit >= 0; bit--) {
-        sink(miller_dbl_step_coop(t, p, gbase, role));
-        if ((k::X_ABS >> bit) & 1) sink(miller_add_step_team(t, q, p, team_lanes8{gbase, role}));
+        sink(miller_dbl_step_team(t, p, team));
+        if ((k::X_ABS >> bit) & 1) sink(miller_add_step_team(t, q, p, team));
     }
 }
 
@@ -2271,14 +2286,17 @@ static void host_combine_chain(const uint8_t rnd[32], size_t n, uint64_t* out) {
 // in flight) that second round overlaps other batches' kernels and one lane per pair is the cheaper form.
 static inline int tail_threads(const mi355_bls_ctx* c) { return c->coop ? TAIL_THREADS : TAIL_THREADS_TP; }
 static void launch_lines(mi355_bls_ctx* c, uint32_t npairs, uint32_t extra, hipStream_t st) {
-    if (c->coop && (npairs + 7) / 8 <= c->slots) {
-        k_lines_coop<<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
+    if (c->coop && (npairs + 3) / 4 <= c->slots / 2) {
+        k_lines_coop<16><<<(npairs + 3) / 4, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
+    } else if (c->coop && (npairs + 7) / 8 <= c->slots) {
+        k_lines_coop<8><<<(npairs + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
     } else if (c->coop && extra && extra < npairs && (extra + 7) / 8 <= c->slots &&
                (npairs + WAVE - 1) / WAVE > c->slots * (((npairs - extra + WAVE - 1) / WAVE + c->slots - 1) / c->slots)) {
         // the extra pairs would start one more round of waves: 8 lanes each instead
         uint32_t main_pairs = npairs - extra;
         k_lines<<<(main_pairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, main_pairs, c->stride, c->d_lines);
-        k_lines_coop<<<(extra + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, main_pairs, extra, c->stride, c->d_lines);
+        if ((extra + 3) / 4 <= c->slots / 2) k_lines_coop<16><<<(extra + 3) / 4, WAVE, 0, st>>>(c->d_P, c->d_H, main_pairs, extra, c->stride, c->d_lines);
+        else k_lines_coop<8><<<(extra + 7) / 8, WAVE, 0, st>>>(c->d_P, c->d_H, main_pairs, extra, c->stride, c->d_lines);
     } else {
         k_lines<<<(npairs + WAVE - 1) / WAVE, WAVE, 0, st>>>(c->d_P, c->d_H, 0, npairs, c->stride, c->d_lines);
     }
