@@ -84,3 +84,19 @@ def test_fast_aggregate_verify_32768(m, cache):
     assert m.verifyAggregate(cache, agg, msg, sig) is True and cache.fetch(4, 576) == gt
     assert m.verifyAggregate(cache, agg, msg, bad) is False
     assert m.verifyAggregate(cache, bytes(144), msg, sig) is False                        # aggregate at infinity
+
+
+@pytest.mark.gpu
+def test_one_message_hash_of_a_32_byte_message(m, cache):
+    """k_hash_one takes 32-byte messages through the batch path's prepared-constants expand_message_xmd and every other length through the byte-wise
+    absorber: both against the C restatement's hash (the signature is made from it), around the boundary."""
+    import c_oracle as co
+    sks = [int.from_bytes(hashlib.sha256(b"h32" + bytes([i])).digest(), "little") % o.R or 1 for i in range(5)]
+    pks = b"".join(co.sk_to_pk(sk) for sk in sks)
+    root = hashlib.sha256(b"a signing root").digest()
+    for msg in (root, root[:31], root + b"\x00", b"", root * 3):
+        hm = co.hash_to_g2(msg, o.DST_SIG)
+        sig, bad = co.g2_mul(hm, sum(sks) % o.R), co.g2_mul(hm, (sum(sks) + 1) % o.R)
+        assert m.fastAggregateVerify(cache, pks, msg, sig) is True, len(msg)
+        assert m.fastAggregateVerify(cache, pks, msg, bad) is False, len(msg)
+    assert m.fastAggregateVerify(cache, pks, root[:31] + bytes([root[31] ^ 1]), co.g2_mul(co.hash_to_g2(root, o.DST_SIG), sum(sks) % o.R)) is False
