@@ -17,6 +17,7 @@ struct c12_work {
     fp prod[108];               // Karatsuba triples (t0, t1, s) of the 36 (or 21) coefficient pairs
     int32_t lo[12][FP_N];       // phase 2a: low 28 bits of every combined limb (top limb: the whole signed value)
     int32_t car[12][FP_N];      // phase 2a: carry into limb l (from limb l - 1)
+    int32_t pl[16];             // the limbs of p (the row phase reads p_l by lane; filled once per kernel: c12_fill_p)
 #ifdef BLS_TAIL_CLOCK
     unsigned long long prof[8]; // diagnostic build: time of thread 0 in each phase of the engine product
 #endif
@@ -121,6 +122,8 @@ BLS_HD int32_t c12_p_limb(int l) {                      // limb l of p, by selec
     return v;
 }
 BLS_HD int64_t c12_sub_qp(int32_t limb, int32_t q, int l) { return (int64_t)limb - (int64_t)q * c12_p_limb(l); }
+BLS_HD int64_t c12_sub_qp_v(int32_t limb, int32_t q, int32_t pl) { return (int64_t)limb - (int64_t)q * pl; }      // p_l from the table (14 compares and selects cost ~340 cycles per product)
+BLS_HD void c12_fill_p(c12_work& W, int t) { if (t < 16) W.pl[t] = t < FP_N ? (int32_t)k::P[t] : 0; }
 // the whole row step on arrays (host harness; the device composes the same pieces with DPP): s[16] -> out limbs [14]
 BLS_HD void c12_row_reduce_ref(const int64_t (&s)[16], int32_t (&out)[FP_N]) {
     int32_t limb[16], car[16];

@@ -808,13 +808,14 @@ __device__ __forceinline__ void c12_phase2_rows(LDS& S, int d) {
     const int t = threadIdx.x, c = t >> 4, l = t & 15;
     const bool live = l < FP_N;
     const int ll = live ? l : 0;
+    const int32_t pl = S.w.pl[l];                                          // issued with the other LDS reads, used at the end
     const c12_lc x = c12_split(c12_limb_sum(S.w, c, ll, SQR), ll);
     const int32_t limb = x.lo + c12_shr1(live ? x.car : 0);
     const int32_t qv = c12_quotient(limb + c12_shr1(limb >> 28));          // right in lane 13 of the row
     const int32_t q0 = __builtin_amdgcn_readlane(qv, 13), q1 = __builtin_amdgcn_readlane(qv, 29), q2 = __builtin_amdgcn_readlane(qv, 45), q3 = __builtin_amdgcn_readlane(qv, 61);
     const int r = (t >> 4) & 3;
     const int32_t q = r == 0 ? q0 : (r == 1 ? q1 : (r == 2 ? q2 : q3));
-    const c12_lc y = c12_split(c12_sub_qp(limb, q, ll), ll);
+    const c12_lc y = c12_split(c12_sub_qp_v(limb, q, pl), ll);
     const int32_t out = y.lo + c12_shr1(live ? y.car : 0);
     if (live) {
         fp2& dst = S.r[d][c >> 1];
@@ -966,6 +967,7 @@ struct fold_lds {
 __global__ void __launch_bounds__(TAIL_THREADS) k_fold(const uint32_t* __restrict__ src, uint32_t count, uint32_t per, uint32_t last_count,
                                                        uint32_t* __restrict__ dst) {
     __shared__ fold_lds S;
+    c12_fill_p(S.w, (int)threadIdx.x);               // visible after the barrier of the first load below
     const uint32_t s = blockIdx.x, b = blockIdx.y, nb = gridDim.y;
     const uint32_t lo = b * per, cnt = b + 1 == nb ? last_count : per;
     const uint32_t* g = src + ((size_t)s * count + lo) * F12W;
@@ -982,6 +984,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_fold(const uint32_t* __restric
 // capacity: every slice commits its own state, the running product lives in slot 1.
 __global__ void __launch_bounds__(TAIL_THREADS) k_state_mul(uint32_t* __restrict__ states, int dst, int a, int b) {
     __shared__ fold_lds S;
+    c12_fill_p(S.w, (int)threadIdx.x);
     c12_load(S, 0, states + (size_t)a * 144);
     if (b >= 0) {
         c12_load(S, 1, states + (size_t)b * 144);
@@ -1022,6 +1025,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
                                                        uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
     __shared__ c12_lds S;
     int lane = threadIdx.x;
+    c12_fill_p(S.w, lane);                           // the row phase's table of p's limbs (visible after the barrier below)
 #ifdef BLS_TAIL_CLOCK
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x < 8) S.w.prof[threadIdx.x] = 0;
