@@ -14,7 +14,7 @@
 namespace bls {
 
 struct c12_work {
-    fp prod[108];               // Karatsuba triples (t0, t1, s) of the 36 (or 21) coefficient pairs
+    fp prod[144];               // the four Fp products (x0 y0, x1 y1, x0 y1, x1 y0) of the 36 (or 21) coefficient pairs (the Karatsuba form: three, 108 slots)
     int32_t lo[12][FP_N];       // phase 2a: low 28 bits of every combined limb (top limb: the whole signed value)
     int32_t car[12][FP_N];      // phase 2a: carry into limb l (from limb l - 1)
     int32_t pl[16];             // the limbs of p (the row phase reads p_l by lane; filled once per kernel: c12_fill_p)
@@ -94,6 +94,59 @@ BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
         W.lo[c][l] = (int32_t)s;
     }
     if (l == 0) W.car[c][0] = 0;
+}
+
+// ---- Schoolbook products (round 4, last form): with one product per lane and lanes to spare, Karatsuba's saved product buys nothing, while its operand sums
+// cost the critical wave 28 extra LDS reads and 28 additions in front of every multiplication.  Item q = 4 pr + kind of pair pr: kind 0: x0 y0, 1: x1 y1,
+// 2: x0 y1, 3: x1 y0 (144 items for a product, 84 for a square) - every lane loads exactly two Fp operands, chosen by ADDRESS.
+BLS_HD void c12s_item(int q, bool sqr, int& i, int& j, int& kx, int& ky) {
+    const int pr = q >> 2, kind = q & 3;
+    if (sqr) {                      // row-by-row enumeration of the pairs i <= j (rows start at 0, 6, 11, 15, 18, 20)
+        i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
+        j = i + pr - (i * 6 - (i * (i - 1)) / 2);
+    } else {
+        i = pr / 6;
+        j = pr % 6;
+    }
+    kx = (kind == 1 || kind == 3) ? 1 : 0;
+    ky = (kind == 1 || kind == 2) ? 1 : 0;
+}
+BLS_HD fp c12s_product(const fp2* A, const fp2* B, int q, bool sqr) {
+    int i, j, kx, ky;
+    c12s_item(q, sqr, i, j, kx, ky);
+    const fp& x = kx ? A[i].c1 : A[i].c0;
+    const fp& y = ky ? B[j].c1 : B[j].c0;
+    return fp_mul(x, y);
+}
+// limb l of coefficient c (kk = c / 2, comp = c % 2) over the six terms: with t = (x0 y0, x1 y1, x0 y1, x1 y0) of a pair,
+//   real:      t0 - t1           wrapped (times xi = 1 + u): t0 - t1 - (t2 + t3)
+//   imaginary: t2 + t3           wrapped:                    t0 - t1 + (t2 + t3)
+// A square's unordered pair {i, j}, i != j, is met twice (the same stored products): that is its factor two.  |sum| <= 24 * 2^28 per low limb.
+BLS_HD int64_t c12s_limb_sum(const c12_work& W, int c, int l, bool sqr) {
+    const int kk = c >> 1, comp = c & 1;
+    int32_t v0[6], v1[6], v2[6], v3[6], cd[6], cx[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int j = kk - i;
+        const bool wrap = j < 0;
+        j += wrap ? 6 : 0;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        const int pr = sqr ? c12_sqr_pair_index(a, b) : i * 6 + j;
+        cd[i] = comp ? (wrap ? 1 : 0) : 1;              // coefficient of (t0 - t1)
+        cx[i] = comp ? 1 : (wrap ? -1 : 0);             // coefficient of (t2 + t3)
+        const fp* t4 = &W.prod[4 * pr];
+        v0[i] = (int32_t)t4[0].l[l];
+        v1[i] = (int32_t)t4[1].l[l];
+        v2[i] = (int32_t)t4[2].l[l];
+        v3[i] = (int32_t)t4[3].l[l];
+    }
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        s = bls_mac(s, cd[i], v0[i] - v1[i]);           // |difference| < 2^29, |sum| < 2^29: exact in 32 bits
+        s = bls_mac(s, cx[i], v2[i] + v3[i]);
+    }
+    return s;
 }
 
 // ---- Phase 2 on rows (round 4): lane (c, l) = (t / 16, t % 16) of a 192-thread block keeps ITS limb in a register from the sum to the stored result;

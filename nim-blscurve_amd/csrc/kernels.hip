@@ -774,31 +774,14 @@ struct c12_lds {
 #define C12_STAMP(i) do { } while (0)
 #endif
 #ifndef BLS_C12_ROW
-// Phase 1 with the KIND of the Karatsuba triple uniform per wave (wave 0: x.c0 y.c0, wave 1: x.c1 y.c1, wave 2: the sums), pair index = lane within
-// the wave: the operand selection is a scalar branch instead of two selects per limb and operand, and only the third wave loads both halves and adds
-// (the lane-per-product enumeration of c12_phase1, which the host harness keeps, had the three kinds in neighbouring lanes: 310 instructions of
-// operand preparation in front of a 700-instruction multiplication).  Blocks of exactly three waves.
-template <int NPAIRS, bool SQR, class LDS>
+// Phase 1, schoolbook (c12.hpp, c12s_*): thread q < 144 (84 for a square) forms ONE Fp product of two operands it picks by address - no operand sums, no selects,
+// the three waves equally loaded (the Karatsuba form, three products per pair with the kind uniform per wave, left the third wave 28 LDS reads and 28
+// additions behind the other two: products 2.8 k cycles + 0.33 k of waiting at the barrier).
+template <int NITEMS, bool SQR, class LDS>
 __device__ __forceinline__ void c12_products(LDS& S, int a, int b) {
-    const int kind = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pr = (int)(threadIdx.x & 63);
-    if (pr < NPAIRS) {
-        int i, j;
-        if (SQR) {
-            i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
-            j = i + pr - (i * 6 - (i * (i - 1)) / 2);
-        } else {
-            i = pr / 6;
-            j = pr % 6;
-        }
-        const fp2 &x = S.r[a][i], &y = S.r[b][j];
-        fp u, v;
-        if (kind == 0) { u = x.c0; v = y.c0; }
-        else if (kind == 1) { u = x.c1; v = y.c1; }
-        else { u = fp_add_nc(x.c0, x.c1); v = fp_add_nc(y.c0, y.c1); }
-        S.w.prod[3 * pr + kind] = fp_mul(u, v);
-    }
+    const int q = (int)threadIdx.x;
+    if (q < NITEMS) S.w.prod[q] = c12s_product(S.r[a], S.r[b], q, SQR);
 }
-// d = a * b (flat basis); d may be a or b.  LDS: any block-shared struct with the registers r[][6] and the work area w.
 // Phase 2 on rows (c12.hpp): thread (c, l) = (t / 16, t % 16) keeps its limb in a register from the 18-term sum to the stored result; carries travel by
 // DPP row shifts, the quotient of the partial reduction comes from lane 13 of the row (v_readlane per row of the wave).  One barrier less per product and
 // ~60 instructions on every lane instead of ~280 on twelve.
@@ -809,7 +792,7 @@ __device__ __forceinline__ void c12_phase2_rows(LDS& S, int d) {
     const bool live = l < FP_N;
     const int ll = live ? l : 0;
     const int32_t pl = S.w.pl[l];                                          // issued with the other LDS reads, used at the end
-    const c12_lc x = c12_split(c12_limb_sum(S.w, c, ll, SQR), ll);
+    const c12_lc x = c12_split(c12s_limb_sum(S.w, c, ll, SQR), ll);
     const int32_t limb = x.lo + c12_shr1(live ? x.car : 0);
     const int32_t qv = c12_quotient(limb + c12_shr1(limb >> 28));          // right in lane 13 of the row
     const int32_t q0 = __builtin_amdgcn_readlane(qv, 13), q1 = __builtin_amdgcn_readlane(qv, 29), q2 = __builtin_amdgcn_readlane(qv, 45), q3 = __builtin_amdgcn_readlane(qv, 61);
@@ -825,7 +808,7 @@ __device__ __forceinline__ void c12_phase2_rows(LDS& S, int d) {
 template <class LDS>
 __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
     C12_T0;
-    c12_products<36, false>(S, a, b);
+    c12_products<144, false>(S, a, b);
     C12_STAMP(0);
     __syncthreads();
     C12_STAMP(1);
@@ -837,7 +820,7 @@ __device__ __noinline__ void c12_mul(LDS& S, int d, int a, int b) {
 // d = a^2: only the 21 pairs i <= j are formed, 63 Fp products
 __device__ __noinline__ void c12_sqr(c12_lds& S, int d, int a) {
     C12_T0;
-    c12_products<21, true>(S, a, a);
+    c12_products<84, true>(S, a, a);
     C12_STAMP(0);
     __syncthreads();
     C12_STAMP(1);

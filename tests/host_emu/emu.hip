@@ -199,10 +199,10 @@ void emu_c12_rowphase(const uint8_t* a576, const uint8_t* b576, int sqr, uint8_t
     fp2 A[6], B[6], D[6];
     for (int t = 0; t < 6; t++) { A[c12_flat_of_tower(t)] = fp2_reduce(*ta[t]); B[c12_flat_of_tower(t)] = fp2_neg(fp2_reduce(fp2_neg(*tb[t]))); }
     static c12_work W;
-    for (int q = 0; q < (sqr ? 63 : 108); q++) W.prod[q] = c12_phase1(A, sqr ? A : B, q, sqr != 0);
+    for (int q = 0; q < (sqr ? 84 : 144); q++) W.prod[q] = c12s_product(A, sqr ? A : B, q, sqr != 0);
     for (int c = 0; c < 12; c++) {
         int64_t s[16] = {0};
-        for (int l = 0; l < FP_N; l++) s[l] = c12_limb_sum(W, c, l, sqr != 0);
+        for (int l = 0; l < FP_N; l++) s[l] = c12s_limb_sum(W, c, l, sqr != 0);
         int32_t o[FP_N];
         c12_row_reduce_ref(s, o);
         fp v;
