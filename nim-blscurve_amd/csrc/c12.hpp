@@ -1,11 +1,11 @@
 // Lane-cooperative Fp12 multiplication / squaring for the per-batch SERIAL tail (Horner over the 68 step products, shard
 // merge, final exponentiation): a handful of Fp12 operations in a dependent chain, so latency is all that matters.
 // An Fp12 value is kept in the flat basis Fp2[w]/(w^6 - xi) (tower slots c0.(a0,a1,a2), c1.(a0,a1,a2) = w^0,2,4 / w^1,3,5).
-// A product is three phases, each a handful of instructions per lane:
-//   1   108 lanes (63 for a square): ONE Fp multiplication each - the Karatsuba triple (t0, t1, s) of every coefficient pair
-//   2a  168 (coefficient, limb) items: the signed limb-wise combination of the 18 products that feed the coefficient,
-//       exact in 64 bits, split into a 28-bit limb and a carry for the next limb
-//   2b  12 lanes: limb + carry, partial reduction (|v| < 0.51 p), result coefficient
+// A product is two phases on a block of three waves, each a handful of instructions per lane (round 4; rounds 1-3 ran Karatsuba triples, a 168-item limb
+// combination and twelve reducing lanes behind three barriers):
+//   1   144 lanes (84 for a square): ONE Fp multiplication each - the four products x0 y0, x1 y1, x0 y1, x1 y0 of every coefficient pair
+//   2   192 lanes = 12 coefficients x 16: lane (c, l) sums the 24 product limbs that feed limb l of coefficient c (exact in 64 bits), passes its carry to
+//       the neighbour, takes the quotient of the partial reduction from lane 13 and stores its limb (|v| < 0.51 p, semi-normalised limbs)
 // The pieces are __host__ __device__ and take the lane / item index as an argument: k_tail calls them with threadIdx.x
 // between barriers, tests/host_emu runs the same code in a loop and compares with the tower's fp12_mul.
 #pragma once
@@ -15,8 +15,6 @@ namespace bls {
 
 struct c12_work {
     fp prod[144];               // the four Fp products (x0 y0, x1 y1, x0 y1, x1 y0) of the 36 (or 21) coefficient pairs (the Karatsuba form: three, 108 slots)
-    int32_t lo[12][FP_N];       // phase 2a: low 28 bits of every combined limb (top limb: the whole signed value)
-    int32_t car[12][FP_N];      // phase 2a: carry into limb l (from limb l - 1)
     int32_t pl[16];             // the limbs of p (the row phase reads p_l by lane; filled once per kernel: c12_fill_p)
 #ifdef BLS_TAIL_CLOCK
     unsigned long long prof[8]; // diagnostic build: time of thread 0 in each phase of the engine product
@@ -27,76 +25,7 @@ BLS_HD int c12_flat_of_tower(int t) { return t < 3 ? 2 * t : 2 * (t - 3) + 1; }
 // index of the pair (i, j), i <= j, in the row-by-row enumeration used for squares: i = 0: j = 0..5 (6), i = 1: 5, ...
 BLS_HD int c12_sqr_pair_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
-// One Fp product of the Karatsuba triple of the coefficient pair (x, y): kind 0: x.c0*y.c0, 1: x.c1*y.c1,
-// 2: (x.c0 + x.c1)(y.c0 + y.c1).
-BLS_HD fp c12_triple(const fp2& x, const fp2& y, int kind) {
-    fp u = kind == 0 ? x.c0 : (kind == 1 ? x.c1 : fp_add_nc(x.c0, x.c1));
-    fp v = kind == 0 ? y.c0 : (kind == 1 ? y.c1 : fp_add_nc(y.c0, y.c1));
-    return fp_mul(u, v);
-}
-
-// phase 1, item q (q < 108: product of A and B; sqr: q < 63, B == A)
-BLS_HD fp c12_phase1(const fp2* A, const fp2* B, int q, bool sqr) {
-    int pr = q / 3, kind = q % 3, i, j;
-    if (sqr) {                      // row-by-row enumeration of the pairs i <= j (rows start at 0, 6, 11, 15, 18, 20), without a search loop
-        i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
-        j = i + pr - (i * 6 - (i * (i - 1)) / 2);
-    } else {
-        i = pr / 6;
-        j = pr % 6;
-    }
-    return c12_triple(A[i], B[j], kind);
-}
-
-// phase 2a, item t < 168: coefficient c = t / 14 (kk = c / 2 the power of w, comp = c % 2 real / imaginary), limb l = t % 14.
-// The Fp2 product of pair (i, j) lands on w^(i+j); wrapped terms (i + j >= 6) are multiplied by xi = 1 + u:
-//   plain:   re = t0 - t1        im = s - t0 - t1
-//   wrapped: re - im = 2 t0 - s  re + im = s - 2 t1
-// Products have limbs 0..12 in [0, 2^28) and a small signed top limb, so the sum of at most 6 * 2 * 4 of them is exact in 64 bits.
-// the signed 64-bit sum of limb l of coefficient c (kk = c / 2 the power of w, comp = c % 2 real / imaginary) over the six terms
-BLS_HD int64_t c12_limb_sum(const c12_work& W, int c, int l, bool sqr) {
-    const int kk = c >> 1, comp = c & 1;
-    int64_t s = 0;
-    // Six terms, no branches (round 4: the loop with its skipped and doubled terms and one LDS round trip per term cost 1 840 cycles per product on the
-    // critical thread, a quarter of the engine's time): a square's unordered pair {i, j}, i != j, is met twice - as (i, j) and as (j, i), the same stored
-    // triple - which IS the factor two; the coefficients of (t0, t1, s) depend on the component and on whether the term wraps around w^6 = xi.
-    int32_t v0[6], v1[6], v2[6], c0[6], c1[6], cs[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {                       // all 18 limbs first (one LDS round trip, not six), then the multiply-adds
-        int j = kk - i;
-        const bool wrap = j < 0;
-        j += wrap ? 6 : 0;
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        const int pr = sqr ? c12_sqr_pair_index(a, b) : i * 6 + j;
-        c0[i] = comp ? (wrap ? 0 : -1) : (wrap ? 2 : 1);
-        c1[i] = comp ? (wrap ? -2 : -1) : (wrap ? 0 : -1);
-        cs[i] = comp ? 1 : (wrap ? -1 : 0);
-        const fp* t3 = &W.prod[3 * pr];
-        v0[i] = (int32_t)t3[0].l[l];
-        v1[i] = (int32_t)t3[1].l[l];
-        v2[i] = (int32_t)t3[2].l[l];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        s = bls_mac(s, c0[i], v0[i]);
-        s = bls_mac(s, c1[i], v1[i]);
-        s = bls_mac(s, cs[i], v2[i]);
-    }
-    return s;
-}
-BLS_HD void c12_phase2a(c12_work& W, int t, bool sqr) {
-    const int c = t / FP_N, l = t % FP_N;
-    const int64_t s = c12_limb_sum(W, c, l, sqr);
-    if (l < FP_N - 1) {
-        W.lo[c][l] = (int32_t)(s & (int64_t)FP_MASK);
-        W.car[c][l + 1] = (int32_t)(s >> 28);
-    } else {
-        W.lo[c][l] = (int32_t)s;
-    }
-    if (l == 0) W.car[c][0] = 0;
-}
-
-// ---- Schoolbook products (round 4, last form): with one product per lane and lanes to spare, Karatsuba's saved product buys nothing, while its operand sums
+// ---- Schoolbook products: with one product per lane and lanes to spare, Karatsuba's saved product buys nothing, while its operand sums
 // cost the critical wave 28 extra LDS reads and 28 additions in front of every multiplication.  Item q = 4 pr + kind of pair pr: kind 0: x0 y0, 1: x1 y1,
 // 2: x0 y1, 3: x1 y0 (144 items for a product, 84 for a square) - every lane loads exactly two Fp operands, chosen by ADDRESS.
 BLS_HD void c12s_item(int q, bool sqr, int& i, int& j, int& kx, int& ky) {
@@ -186,17 +115,6 @@ BLS_HD void c12_row_reduce_ref(const int64_t (&s)[16], int32_t (&out)[FP_N]) {
     int32_t lo2[16], car2[16];
     for (int l = 0; l < FP_N; l++) { c12_lc x = c12_split(c12_sub_qp(limb[l], q, l), l); lo2[l] = x.lo; car2[l] = x.car; }
     for (int l = 0; l < FP_N; l++) out[l] = lo2[l] + (l ? car2[l - 1] : 0);
-}
-
-// phase 2b, coefficient c < 12: the value (|v| <= 36 p: six terms of at most three products of |v| < 2p each, doubled at most)
-// partially reduced, so that bounds never accumulate along a chain of products
-BLS_HD fp c12_phase2b(const c12_work& W, int c) {
-    fp v;
-#pragma unroll
-    for (int l = 0; l < FP_N; l++) v.l[l] = (uint32_t)(W.lo[c][l] + W.car[c][l]);
-    BLS_SET_VB(v, 36);
-    BLS_SET_LB(v, 1);
-    return fp_reduce(v);
 }
 
 // ---- Row engine (round 4): one Fp12 product = 12 output coefficients x 12 Fp product terms, one 16-lane row per coefficient ------------

@@ -154,22 +154,6 @@ unsigned long long emu_mad_census(int stage, const uint8_t* set320, uint64_t r) 
     return 0;
 #endif
 }
-// the lane-cooperative Fp12 engine of k_tail, run item by item (what the lanes do between barriers)
-static void emu_c12_run(const uint8_t* a576, const uint8_t* b576, uint8_t* out576, bool sqr) {
-    fp12 fa = fp12_load_le(a576), fb = fp12_load_le(b576);
-    const fp2* ta[6] = {&fa.c0.a0, &fa.c0.a1, &fa.c0.a2, &fa.c1.a0, &fa.c1.a1, &fa.c1.a2};
-    const fp2* tb[6] = {&fb.c0.a0, &fb.c0.a1, &fb.c0.a2, &fb.c1.a0, &fb.c1.a1, &fb.c1.a2};
-    fp2 A[6], B[6], D[6];
-    for (int t = 0; t < 6; t++) { A[c12_flat_of_tower(t)] = fp2_reduce(*ta[t]); B[c12_flat_of_tower(t)] = fp2_reduce(*tb[t]); }
-    static c12_work W;
-    for (int q = 0; q < (sqr ? 63 : 108); q++) W.prod[q] = c12_phase1(A, sqr ? A : B, q, sqr);
-    for (int t = 0; t < 12 * FP_N; t++) c12_phase2a(W, t, sqr);
-    for (int c = 0; c < 12; c++) { fp v = c12_phase2b(W, c); if (c & 1) D[c >> 1].c1 = v; else D[c >> 1].c0 = v; }
-    fp12 r;
-    fp2* tr[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
-    for (int t = 0; t < 6; t++) *tr[t] = D[c12_flat_of_tower(t)];
-    fp12_store_le(out576, r);
-}
 // the row engine (c12r_*): 12 rows x 16 lanes, row sums in a loop here (DPP on the device)
 void emu_c12r_mul(const uint8_t* a576, const uint8_t* b576, uint8_t* out576) {
     fp12 a = fp12_load_le(a576), b = fp12_load_le(b576), r;
@@ -191,7 +175,8 @@ void emu_c12r_mul(const uint8_t* a576, const uint8_t* b576, uint8_t* out576) {
     for (int t = 0; t < 6; t++) *tr[t] = D[c12_flat_of_tower(t)];
     fp12_store_le(out576, r);
 }
-// the Karatsuba engine with the row form of its second phase (c12_limb_sum + c12_row_reduce_ref: what the device does with DPP row shifts)
+// the lane-cooperative Fp12 engine of k_tail, run item by item (what the lanes do between barriers): schoolbook products (c12s_product), the limb sums of
+// every output coefficient (c12s_limb_sum) and the row reduction (c12_row_reduce_ref: what the device does with DPP row shifts); one operand with negated limbs
 void emu_c12_rowphase(const uint8_t* a576, const uint8_t* b576, int sqr, uint8_t* out576) {
     fp12 fa = fp12_load_le(a576), fb = fp12_load_le(b576);
     const fp2* ta[6] = {&fa.c0.a0, &fa.c0.a1, &fa.c0.a2, &fa.c1.a0, &fa.c1.a1, &fa.c1.a2};
@@ -215,6 +200,6 @@ void emu_c12_rowphase(const uint8_t* a576, const uint8_t* b576, int sqr, uint8_t
     for (int t = 0; t < 6; t++) *tr[t] = D[c12_flat_of_tower(t)];
     fp12_store_le(out576, r);
 }
-void emu_c12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { emu_c12_run(a, b, out, false); }
-void emu_c12_sqr(const uint8_t* a, uint8_t* out) { emu_c12_run(a, a, out, true); }
+void emu_c12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { emu_c12_rowphase(a, b, 0, out); }
+void emu_c12_sqr(const uint8_t* a, uint8_t* out) { emu_c12_rowphase(a, a, 1, out); }
 }

@@ -323,7 +323,7 @@ def test_lane_cooperative_fp12_engine(emu):
         assert got == call(emu, "emu_fp12_mul", A, B, outlen=576)
         assert fp12_from_bytes(got) == o.f12mul(a, b)
         assert fp12_from_bytes(call(emu, "emu_c12_sqr", A, outlen=576)) == o.f12sqr(a)
-        # the row form of the engine's second phase (limbs stay in their lanes: carries by neighbour, quotient from lane 13)
+        # the engine called with explicit product / square flag (limbs stay in their lanes: carries by neighbour, quotient from lane 13)
         assert fp12_from_bytes(call(emu, "emu_c12_rowphase", A, B, 0, outlen=576)) == o.f12mul(a, b)
         assert fp12_from_bytes(call(emu, "emu_c12_rowphase", A, A, 1, outlen=576)) == o.f12sqr(a)
         # the row engine (one 16-lane row per output coefficient, one reduction per row)
