@@ -54,7 +54,11 @@ MAD_PEAK_MEASURED = 256 * 4 * 64 / 2.28e-9      # multiply-adds/s the chip issue
 # The CEILING for this arithmetic: back-to-back lazily reduced dot products (588 multiply-adds + 69 other instructions each) with no
 # caller code at all, every SIMD busy (tools/ubench_fp2chain.hip, profiles/r04_ubench_fp2chain.txt): 30.39 T multiply-adds/s - the
 # chip holds 2.17 GHz under that stream and issues an instruction per 4.09 cycles
-MAD_CEILING = 30.39e12
+MAD_CEILING = 30.39e12          # the committed figure; the run measures it again on its own box (measure_ceiling)
+# algorithmic HBM bytes per tuple of the WHOLE path, SURVEY.md section 8(d): one 320-byte SignatureSet read per verification
+PATH_BYTES_PER_TUPLE = 320
+# the fixed per-kernel table of the roofline object (the wide kernels of one batch, in pipeline order)
+ROOFLINE_KERNELS = ("k_hash_map", "k_hash_clear", "k_pkmul", "k_sig_bucket", "k_lines", "k_lineprod")
 # which stage timer (HIP events inside the library) measures which single kernel
 KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
 
@@ -114,6 +118,45 @@ def spawn_ranks(a):
         return 1
     print(lines[-1], flush=True)
     return 0
+
+
+def measure_ceiling():
+    """tools/ubench_fp2chain.bin on THIS box (a child process, ~50 ms of GPU time before the timed region): back-to-back lazily reduced
+    dot products with no caller code on every SIMD - the most any kernel built on this multiplier can reach.  None if the binary is
+    missing or fails (the committed figure of profiles/r04_ubench_fp2chain.txt is then the fallback, and the line says so)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench_fp2chain.bin")
+    try:
+        out = subprocess.run([exe, "4000", "0"], capture_output=True, text=True, timeout=120).stdout
+        mm = re.search(r"cycles/instr ([0-9.]+)\s+in-kernel clock ([0-9.]+) GHz\s+multiply-adds/s ([0-9.]+) T", out)
+        return {"mads_per_s": float(mm.group(3)) * 1e12, "cycles_per_instr": float(mm.group(1)), "clock_ghz": float(mm.group(2))}
+    except Exception:
+        return None
+
+
+def dist_info(world, backend, ctl, dev):
+    """What stands behind an N > 1 line: backend, world size, RCCL version and the identity of every rank's device, gathered over the
+    gloo control group - N distinct devices means N GPUs were really used."""
+    try:
+        prop = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(prop, "uuid", "")) or ""
+    except Exception:
+        ident = ""
+    if not ident or set(ident) <= set("0-"):
+        ident = "hip-device"
+    ident = "%s/dev%d" % (ident, dev.index)
+    objs = [None] * world
+    if world > 1:
+        dist.all_gather_object(objs, ident, group=ctl)
+    else:
+        objs = [ident]
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {"backend": backend, "is_rccl": backend == "nccl", "world_size": world, "nccl_version": ver, "device_uuids": objs,
+            "distinct_devices": len(set(objs)), "all_on_device0_test_hook": os.environ.get("BENCH_ALL_ON_DEVICE0") == "1"}
 
 
 def next_rnd(rnd):
@@ -387,6 +430,7 @@ def main():
     ap.add_argument("--no-one-caller", action="store_true", help="skip the one-blocking-caller measurements after the timed region (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (shards + collective) even with one rank")
     ap.add_argument("--msm-log2", type=int, default=20, help="N > 1: log2 of the points per GPU of the multi-GPU MSM rows (tests pass a small value)")
+    ap.add_argument("--no-ceiling", action="store_true", help="do not run tools/ubench_fp2chain.bin before the timed region")
     ap.add_argument("--exchange", choices=["device", "host"], default=os.environ.get("BENCH_EXCHANGE", "device"),
                     help="N > 1: all_gather of device-resident shard blobs (RCCL, no host round trip) or of host bytes")
     a = ap.parse_args()
@@ -422,6 +466,13 @@ def main():
 
     ge.build()
     m = ge.load_package()
+    binfo = m.build_info()
+    if not binfo["aligned"] and os.environ.get("BLS_NO_ALIGN") != "1":
+        sys.stderr.write("bench.py: the library was built WITHOUT the instruction-alignment post-pass (%s); numbers from it are not the product's. "
+                         "Rebuild (nim-blscurve_amd/build.sh -f) or set BLS_NO_ALIGN=1 to measure it on purpose.\n" % binfo)
+        sys.exit(2)
+    ceiling_live = measure_ceiling() if (rank == 0 and not a.no_ceiling) else None
+    dinfo = dist_info(world, backend, ctl, dev) if sharded_path else None
 
     n = a.batch
     run = ShardedRun(m, a, dev, local, rank, world, backend, ctl, n, sharded_path)
@@ -461,12 +512,25 @@ def main():
         mad_total = sum(MAD_PER_TUPLE.values())
         mad_peak = prop.multi_processor_count * 4 * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
         mad_achieved = mad_total * n / (ms_per_step * 1e-3)
-        # the dominant kernel = the one with the most multiply-add WORK per batch (the bound of this path), not the longest
-        # un-overlapped duration (which a nearly empty second round of waves can inflate)
-        dom = max((k for k in alone if k in KERNEL_BYTES), key=lambda k: MAD_PER_TUPLE.get(k, 0))
-        alg_bytes = KERNEL_BYTES[dom] * n
-        dom_ms = timed_kernel_ms.get(dom, alone[dom])
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # One definition, the same every round: the WHOLE path at SURVEY.md 8(d)'s 320 bytes per tuple over the step time against the
+        # HBM peak (a unit = one verification, a "launch" = one batch step), and a FIXED per-kernel table beside it - no "dominant
+        # kernel" whose choice changes the number.  The bound that matters is the integer multiply-add issue rate (int_mad below).
+        achieved = PATH_BYTES_PER_TUPLE * n / (ms_per_step * 1e-3) / 1e9
+        ktab, traffic_total, traffic_src = {}, 0.0, None
+        for k in ROOFLINE_KERNELS:
+            tr, src = pmc_traffic(k)
+            traffic_src = traffic_src or src
+            ms_alone = alone.get(k)
+            row = {"algorithmic_bytes": KERNEL_BYTES.get(k, 0) * n, "mad_per_tuple": MAD_PER_TUPLE.get(k), "hbm_traffic_bytes": tr,
+                   "ms_alone": round(ms_alone, 4) if ms_alone else None, "ms_timed_region": round(timed_kernel_ms[k], 4) if k in timed_kernel_ms else None}
+            if ms_alone:
+                row["algorithmic_GBs_alone"] = KERNEL_BYTES.get(k, 0) * n / (ms_alone * 1e-3) / 1e9
+                row["hbm_util_alone"] = (tr / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None
+                row["int_mad_frac_alone"] = MAD_PER_TUPLE[k] * n / (ms_alone * 1e-3) / mad_peak
+            if tr:
+                traffic_total += tr
+            ktab[k] = row
+        ceil_v = ceiling_live["mads_per_s"] if ceiling_live else MAD_CEILING
         out = {
             "metric": "BLS sig verifications/sec (batch)",
             "value": n_total * a.steps / dt,
@@ -492,30 +556,33 @@ def main():
             "ms_host_buffers": one.get("ms_host_buffers"),
             "value_one_caller_sliced": one.get("value_one_caller_sliced"),
             "ms_one_caller_sliced_2^20": one.get("ms_one_caller_sliced_2^20"),
-            "roofline": {"bound": "hbm", "bound_actual": "int_mad", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
-                         "kernel_ms_timed_region": dom_ms, "kernel_ms_alone": alone[dom],
-                         "achieved_kernel_alone": alg_bytes / (alone[dom] * 1e-3) / 1e9,
-                         "frac_kernel_alone": alg_bytes / (alone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "whole_path_GBs_at_320B_per_tuple": 320.0 * n / (ms_per_step * 1e-3) / 1e9,
-                         "whole_path_frac": 320.0 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "int_mad", "bound_note": "of the contract's two choices (hbm | mfma) this is the hbm line: achieved / peak / frac below are HBM "
+                                                           "figures; what actually bounds the path is the integer multiply-add issue rate, int_mad",
+                         "kernel": "whole path (one batch step: k_blind .. k_tail)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_unit": PATH_BYTES_PER_TUPLE, "units_per_launch": n,
+                         "traffic": traffic_total or None, "traffic_source": traffic_src,
+                         "traffic_note": "sum over the six wide kernels of their PMC-measured HBM bytes per launch (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE)",
+                         "kernels": ktab,
                          "int_mad": {"achieved": mad_achieved / 1e12, "peak": mad_peak / 1e12, "unit": "T multiply-adds/s",
                                      "frac": mad_achieved / mad_peak, "mad_per_tuple": mad_total,
                                      "model": "census of the kernels' formulas (MAD_PER_TUPLE) x tuples / ms_per_step; peak = CUs x 4 SIMDs x 64 lanes x "
                                               "2.4 GHz / 4 cycles per v_mad_i64_i32",
-                                     "per_kernel_frac_alone": {k: MAD_PER_TUPLE[k] * n / (alone[k] * 1e-3) / mad_peak
-                                                               for k in alone if k in MAD_PER_TUPLE and alone[k] > 0},
-                                     "ceiling": {"achievable": MAD_CEILING / 1e12, "frac_of_peak": MAD_CEILING / mad_peak, "achieved_over_ceiling": mad_achieved / MAD_CEILING,
-                                                 "source": "tools/ubench_fp2chain.hip (profiles/r04_ubench_fp2chain.txt): back-to-back dot-product bodies, zero caller "
-                                                           "code, one wave per SIMD on every SIMD"},
+                                     "ceiling": {"achievable": ceil_v / 1e12, "frac_of_peak": ceil_v / mad_peak, "achieved_over_ceiling": mad_achieved / ceil_v,
+                                                 "measured_on_this_box": ceiling_live is not None,
+                                                 "cycles_per_instr": ceiling_live["cycles_per_instr"] if ceiling_live else None,
+                                                 "clock_ghz": ceiling_live["clock_ghz"] if ceiling_live else None,
+                                                 "source": "tools/ubench_fp2chain.bin run by this process before the timed region: back-to-back dot-product bodies, zero "
+                                                           "caller code, one wave per SIMD on every SIMD" if ceiling_live else
+                                                           "profiles/r04_ubench_fp2chain.txt (the binary did not run here)"},
                                      "peak_measured": MAD_PEAK_MEASURED / 1e12,
                                      "frac_of_measured": mad_achieved / MAD_PEAK_MEASURED,
                                      "peak_measured_note": "tools/ubench_valu.hip on this chip (profiles/r01_ubench_valu.txt): a stream of independent "
                                                            "v_mad_u64_u32 issues one per 2.28 ns per SIMD at 4 waves per SIMD (2.41 at 8, 2.87 at 1), "
                                                            "not one per 4 cycles at 2.4 GHz = 1.67 ns"},
                          "note": "the path is integer multiply-add bound, not HBM bound (1.2e4 multiply-adds per input byte): int_mad is the roofline "
-                                 "that says how good the kernels are; the HBM fraction is reported because the contract asks for it.  The dominant kernel "
-                                 "is the one with the most multiply-add work per batch"},
+                                 "that says how good the kernels are; the HBM fraction (320 B per verification over the step time) is what the contract asks for"},
+            "build": binfo,
+            "dist": dinfo,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "kernel_ms_timed_region": {k: round(v, 3) for k, v in timed_kernel_ms.items()},
             "kernel_ms_alone": {k: round(v, 3) for k, v in alone.items()},

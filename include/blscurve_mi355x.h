@@ -49,6 +49,10 @@ typedef struct mi355_bls_ctx mi355_bls_ctx;
 int mi355_bls_ctx_create(mi355_bls_ctx** out, int device, size_t max_sets);
 void mi355_bls_ctx_destroy(mi355_bls_ctx* ctx);
 const char* mi355_bls_last_error(void);
+/* How the loaded library was built: "aligned=1 dpp_combine=off stamp=<sha256 of its sources>".  aligned=0 = built without the
+ * instruction-alignment post-pass (BLS_NO_ALIGN=1; ~23 % lower issue rate of the multiply-add streams): a measurement taken with
+ * such a library says so (bench.py prints the string and refuses aligned=0 unless asked).  Static string, never NULL. */
+const char* mi355_bls_build_info(void);
 
 /* HIP hardware queues.  HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
  * queue run strictly in turn.  Whole-chip batches do not care; a host that keeps MANY SMALL batches in flight (one context + stream
@@ -108,7 +112,8 @@ int mi355_bls_batch_wait(mi355_bls_ctx* ctx);
  * partition B = min(n_b, num_threads), serial chain for n_b < 3 or num_threads = 1, bls_batch_verifier.nim:440); the union is
  * verified at once, and the product of the k batch checks is one iff every batch verifies (up to the 2^-64 of the random linear
  * combination, the reference's own bound).  If it is not, or if the union exceeds the context's capacity, the batches are
- * verified one by one.  Returns 1 when every batch verified, 0 otherwise, negative on runtime failure.  * REQUIREMENT for the merged pass: the k secureRandomBytes must be pairwise independent.  The library checks what it can: if any two
+ * verified one by one.  Returns 1 when every batch verified, 0 otherwise, negative on runtime failure.
+ * REQUIREMENT for the merged pass: the k secureRandomBytes must be pairwise independent.  The library checks what it can: if any two
  * non-empty batches carry the SAME 32 bytes (their blinding chains would coincide and errors could cancel ACROSS batches, which k
  * separate calls would not allow), no merged pass is made and the batches are verified one by one - the verdicts stay those of k
  * separate calls, only the speed-up is lost.  Draw one fresh rnd per batch.

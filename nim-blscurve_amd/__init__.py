@@ -15,7 +15,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblscurve_mi355x.so")
+# MI355_BLS_LIB: another build of the same library (the A/B scripts under tools/ point it at nim-blscurve_amd/variants/<name>.so
+# instead of copying a variant over the shipped file)
+LIB_PATH = os.environ.get("MI355_BLS_LIB") or os.path.join(_HERE, "libblscurve_mi355x.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "blscurve_mi355x.h"))
 
 SIGSET_BYTES = 320
@@ -47,6 +49,7 @@ def lib():
         L.mi355_bls_ctx_destroy.argtypes = [vp]
         L.mi355_bls_ctx_destroy.restype = None
         L.mi355_bls_last_error.restype = ctypes.c_char_p
+        L.mi355_bls_build_info.restype = ctypes.c_char_p
         L.mi355_bls_ctx_set_num_threads.argtypes = [vp, u32]
         L.mi355_bls_ctx_set_cooperative.argtypes = [vp, i32]
         L.mi355_bls_batch_verify.argtypes = [vp, vp, sz, ctypes.c_char_p]
@@ -130,6 +133,12 @@ def lib():
         L.mi355_bls_last_kernel_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib
+
+
+def build_info():
+    """mi355_bls_build_info() as a dict: {"aligned": bool, "dpp_combine_off": bool, "stamp": str}."""
+    kv = dict(x.split("=", 1) for x in lib().mi355_bls_build_info().decode().split())
+    return {"aligned": kv.get("aligned") == "1", "dpp_combine_off": kv.get("dpp_combine") == "off", "stamp": kv.get("stamp", "unknown")}
 
 
 def _check(rc):

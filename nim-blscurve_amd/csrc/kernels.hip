@@ -2031,6 +2031,19 @@ static const char DST_SIG[] = "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";   /
 
 extern "C" const char* mi355_bls_last_error(void) { return g_err.c_str(); }
 
+// How this library was built (build.sh passes the three macros to the host compile): "aligned=1 dpp_combine=off stamp=<sha256 of the
+// sources>".  aligned=0 means the instruction-alignment post-pass (tools/align_isa.py) was skipped - an 8-byte VALU stream then issues
+// ~23 % slower - which build.sh only does when BLS_NO_ALIGN=1 asks for it; bench.py prints the string with its numbers.
+#ifndef BLS_BUILD_ALIGNED
+#define BLS_BUILD_ALIGNED -1
+#endif
+#ifndef BLS_BUILD_STAMP
+#define BLS_BUILD_STAMP "unknown"
+#endif
+#define BLS_STR2(x) #x
+#define BLS_STR(x) BLS_STR2(x)
+extern "C" const char* mi355_bls_build_info(void) { return "aligned=" BLS_STR(BLS_BUILD_ALIGNED) " dpp_combine=off stamp=" BLS_BUILD_STAMP; }
+
 extern "C" void mi355_bls_ctx_destroy(mi355_bls_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -2184,8 +2197,14 @@ static int io_reserve(mi355_bls_ctx* c, size_t n) {
     // only this context's own work can still read the old buffers, and no call is pending (checked above; blocking calls return after
     // their stream has drained): the fork stream and the stream of the last call are waited for, never the whole device (other
     // contexts keep running)
-    if (c->side) HIPCHK(hipStreamSynchronize(c->side));
-    if (c->pending_stream) HIPCHK(hipStreamSynchronize(c->pending_stream));
+    // (pending_stream is cleared by every wait: a handle kept from an earlier call may belong to a stream the host has destroyed since)
+    hipError_t se = c->side ? hipStreamSynchronize(c->side) : hipSuccess;
+    if (se == hipSuccess && c->pending_stream) se = hipStreamSynchronize(c->pending_stream);
+    if (se != hipSuccess) {
+        for (int i = 0; i < 4; i++) (void)hipFree(nb[i]);
+        g_err = std::string("io_reserve: hipStreamSynchronize: ") + hipGetErrorString(se);
+        return MI355_BLS_ERR_HIP;
+    }
     void** bufs[] = {(void**)&c->d_sets, (void**)&c->d_comp, (void**)&c->d_status, (void**)&c->d_r};
     for (int i = 0; i < 4; i++) {
         if (*bufs[i]) (void)hipFree(*bufs[i]);
@@ -2438,22 +2457,41 @@ __global__ void k_or_flag(uint32_t* __restrict__ dst, const uint32_t* __restrict
     if (threadIdx.x == 0 && blockIdx.x == 0 && src[0]) atomicOr(dst, src[0]);
 }
 // the internal workspaces of pipelined slices: same device, same capacity, throughput mode (no fork streams: the slices overlap each other)
+// Returns the number of lanes usable (0 .. want): a lane is published only when its workspace, its stream and its event all exist,
+// and a lane that cannot be created (out of memory: a workspace is ~29 KB per set) is not an error - the slices then run on fewer
+// workspaces, down to this context's own (the serial slice loop of round 3).  Negative: the events every sliced call needs failed.
 static int ensure_lanes(mi355_bls_ctx* c, int want) {
     if (!c->ev_sl0) HIPCHK(hipEventCreateWithFlags(&c->ev_sl0, hipEventDisableTiming));
     for (auto& e : c->ev_blind)
         if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int have = 0;
     for (int k = 0; k < want && k < 2; k++) {
-        if (c->lane[k]) continue;
+        if (c->lane[k]) {
+            have = k + 1;
+            continue;
+        }
         mi355_bls_ctx* x = nullptr;
-        int rc = mi355_bls_ctx_create(&x, c->device, c->cap);
-        if (rc) return rc;
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        if (mi355_bls_ctx_create(&x, c->device, c->cap) != 0) x = nullptr;
+        if (x && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+        if (x && s && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        if (!x || !s || !e) {
+            if (e) (void)hipEventDestroy(e);
+            if (s) (void)hipStreamDestroy(s);
+            if (x) mi355_bls_ctx_destroy(x);
+            (void)hipGetLastError();                // an out-of-memory error is sticky until read
+            (void)hipSetDevice(c->device);
+            break;
+        }
         x->is_lane = true;
         x->coop = false;
+        c->lane_st[k] = s;
+        c->lane_ev[k] = e;
         c->lane[k] = x;
-        HIPCHK(hipStreamCreateWithFlags(&c->lane_st[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+        have = k + 1;
     }
-    return 0;
+    return have;
 }
 // A shard = chunks [chunk_lo, chunk_lo + chunk_cnt) = tuples [tuple_base, tuple_base + n) of the global batch -> committed state in
 // d_states slot 0.  The reference's cache holds per-thread pairing contexts only and accepts any input.len
@@ -2492,10 +2530,11 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* src_dev, const uint8_t* sr
     // slice's k_blind left: ev_blind), and each workspace's own stream.  Every workspace keeps the running product of ITS slices in
     // slot 1 of its d_states; at the end the lanes' products are copied over and multiplied in (an Fp12 product commutes).  The last
     // slice always runs in this context's own workspace, so fetch_stage(0..3) shows it as before.
-    const int nl = nslices >= 3 ? 3 : 2;                      // workspaces used, this context's included
+    int nl = nslices >= 3 ? 3 : 2;                            // workspaces used, this context's included
     {
-        int rcl = ensure_lanes(c, nl - 1);
-        if (rcl) return rcl;
+        int have = ensure_lanes(c, nl - 1);
+        if (have < 0) return have;
+        nl = have + 1;                                         // fewer lanes than wanted (memory): fewer slices in flight, down to one after the other
     }
     HIPCHK(hipEventRecord(c->ev_sl0, st));                     // rnd uploaded, flags cleared
     for (int k = 0; k < nl - 1; k++) {
@@ -2523,7 +2562,15 @@ static int run_shard(mi355_bls_ctx* c, const uint8_t* src_dev, const uint8_t* sr
         const uint8_t* d = src_dev ? src_dev + 320 * done : x->d_sets;
         if (!src_dev) HIPCHK(hipMemcpyAsync(x->d_sets, src_host + 320 * done, cnt * 320, hipMemcpyHostToDevice, sx));
         int rc = run_slice(x, c, d, n_total, nchunks, c_lo, c_hi - c_lo, t0, cnt, serial, done, slice, sx, c->ev_blind[slice % 3]);
-        if (rc) return rc;
+        if (rc) {
+            // earlier slices are still running on the lane streams and read the caller's records and this context's chain state: drain
+            // them before the error goes back (the caller may free its buffers then); the error of the failed enqueue is what is reported
+            std::string keep = g_err;
+            for (int k = 0; k < nl - 1; k++) (void)hipStreamSynchronize(c->lane_st[k]);
+            (void)hipStreamSynchronize(st);
+            g_err = keep;
+            return rc;
+        }
         k_state_mul<<<1, TAIL_THREADS, 0, sx>>>(x->d_states, 1, used[L] ? 1 : 0, used[L] ? 0 : -1);
         used[L] = true;
         prev = x;
@@ -2586,7 +2633,11 @@ static int verify_wait(mi355_bls_ctx* c) {
     if (!c || !c->pending) return MI355_BLS_ERR_ARG;
     c->pending = false;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->pending_stream));
+    {
+        hipStream_t ps = c->pending_stream;
+        c->pending_stream = nullptr;              // the host may destroy its stream after this call: never keep the handle
+        HIPCHK(hipStreamSynchronize(ps));
+    }
     c->have_gt = true;
     float fin = 0;
     int rc = collect_timings(c, 7);
@@ -2808,7 +2859,11 @@ static int shard_wait(mi355_bls_ctx* c, uint8_t out_fp12[576], int* out_ok) {
     if (!c || !out_fp12 || !out_ok || !c->pending) return MI355_BLS_ERR_ARG;
     c->pending = false;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->pending_stream));
+    {
+        hipStream_t ps = c->pending_stream;
+        c->pending_stream = nullptr;
+        HIPCHK(hipStreamSynchronize(ps));
+    }
     std::memcpy(out_fp12, c->h_flags + 16, 576);
     *out_ok = c->h_flags[0] == 0 ? 1 : 0;
     return collect_timings(c, 7);

@@ -36,6 +36,7 @@ def test_rccl_exchange_with_one_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["exchange"] == {"mode": "device"} and d["value"] > 0
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["is_rccl"] and d["dist"]["world_size"] == 1 and d["dist"]["nccl_version"]
 
 
 def test_bench_spawns_its_own_ranks():
@@ -73,6 +74,16 @@ def test_eight_ranks_dry_run_on_one_gpu():
     c5 = d["multi_gpu"]["config5_shape_batchVerify"]
     assert c5["tuples_per_gpu"] == 8192 and c5["global_batch"] == 8 * 8192 and c5["verifications_per_s"] > 0
     assert d["multi_gpu"]["g1_msm"]["weak_2^14_per_gpu"]["points_total"] == 8 << 14
+    # what stands behind the N > 1 line (round-4 review): backend, world size and one device identity per rank, over the control group
+    di = d["dist"]
+    assert di["backend"] == "gloo" and di["is_rccl"] is False and di["world_size"] == 8 and len(di["device_uuids"]) == 8
+    assert di["distinct_devices"] == 1 and di["all_on_device0_test_hook"] is True        # the dry run: eight ranks on ONE device, and the line says so
+    assert d["build"]["aligned"] is True and d["build"]["dpp_combine_off"] is True and len(d["build"]["stamp"]) == 64
+    rf = d["roofline"]
+    assert rf["bound"] == "int_mad" and rf["algorithmic_bytes_per_unit"] == 320 and rf["units_per_launch"] == 4096
+    assert abs(rf["frac"] - 320 * 4096 / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-9
+    assert set(rf["kernels"]) == {"k_hash_map", "k_hash_clear", "k_pkmul", "k_sig_bucket", "k_lines", "k_lineprod"}
+    assert rf["int_mad"]["ceiling"]["measured_on_this_box"] is True and 0.5 < rf["int_mad"]["ceiling"]["frac_of_peak"] < 1.0
 
 
 def test_a_dying_rank_fails_the_run():

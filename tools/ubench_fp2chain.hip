@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include "ubench_fp2chain.inc"
 constexpr int BODIES = 4, MADS_PER_BODY = 588, INSTR_PER_BODY = 657;
 __global__ void __launch_bounds__(64) k(uint32_t* out, uint64_t* stamps, int iters) {
@@ -39,9 +40,18 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, uint64_t* stamps, int ite
     out[blockIdx.x * 64 + threadIdx.x] = res;
     if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
-int main() {
-    for (int blocks : {1024, 128}) {
-        uint32_t* out; uint64_t* st; int iters = 20000;
+int main(int argc, char** argv) {
+    // usage: ubench_fp2chain.bin [iters [waves]]   (bench.py runs "4000 0": ~20 ms on every SIMD of the chip, one line of output)
+    const int iters_arg = argc > 1 ? atoi(argv[1]) : 20000;
+    int nsimd = 1024;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, 0) == hipSuccess) nsimd = 4 * prop.multiProcessorCount;
+    }
+    const int only = argc > 2 ? atoi(argv[2]) : -1;          // 0: the whole chip only
+    for (int blocks : {nsimd, nsimd / 8}) {
+        if (only == 0 && blocks != nsimd) continue;
+        uint32_t* out; uint64_t* st; int iters = iters_arg;
         (void)hipMalloc(&out, (size_t)blocks * 64 * 4); (void)hipMalloc(&st, blocks * 16);
         k<<<blocks, 64>>>(out, st, 200);
         (void)hipDeviceSynchronize();
@@ -53,9 +63,9 @@ int main() {
         uint64_t h[2]; (void)hipMemcpy(h, st + 2 * (blocks / 2), 16, hipMemcpyDeviceToHost);
         double instr = (double)iters * BODIES * INSTR_PER_BODY, mads = (double)iters * BODIES * MADS_PER_BODY;
         double rate = mads * 64.0 * blocks / (ms * 1e-3);                 // multiply-adds per second, whole launch
-        double peak = 1024.0 * 64 * 2.4e9 / 4;
+        double peak = (double)nsimd * 64 * 2.4e9 / 4;
         printf("dot2 chain, %4d waves: cycles/instr %.3f  in-kernel clock %.3f GHz  multiply-adds/s %.2f T  (%.3f of the nominal peak %.1f T when all 1024 SIMDs run)\n", blocks,
-               (double)h[0] / instr, (double)h[0] / ((double)h[1] * 10.0), rate / 1e12, rate * (1024.0 / blocks) / peak, peak / 1e12);
+               (double)h[0] / instr, (double)h[0] / ((double)h[1] * 10.0), rate / 1e12, rate * ((double)nsimd / blocks) / peak, peak / 1e12);
     }
     return 0;
 }
