@@ -117,71 +117,4 @@ BLS_HD void c12_row_reduce_ref(const int64_t (&s)[16], int32_t (&out)[FP_N]) {
     for (int l = 0; l < FP_N; l++) out[l] = lo2[l] + (l ? car2[l - 1] : 0);
 }
 
-// ---- Row engine (round 4): one Fp12 product = 12 output coefficients x 12 Fp product terms, one 16-lane row per coefficient ------------
-// c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j with xi b = (b0 - b1) + (b0 + b1) u, so the real and the imaginary part of every c_k
-// are sums of exactly 12 Fp products x * y (x a half of a_i, y = +-b_j0 +- b_j1, a limb-wise combination).  Thread (row, q), row = 2 k + part,
-// q = 2 i + h < 12, forms ONE unreduced product (196 multiply-adds), carries it into 28 limbs, the 16 lanes of the row add their limbs
-// (DPP row shifts on the device, a loop in the host harness), and one lane per row runs ONE Montgomery reduction over the 28 limb sums:
-// about 900 instructions and two barriers per Fp12 product in place of a full Fp multiplication per lane plus the 168-item limb combination
-// and three barriers of the Karatsuba engine above (3.7 -> ~2 us per product in the serial tail).
-// Operand limbs: |a| < 2^28 (+ slack), y = s0 b0 + s1 b1 with |limb| < 2^29: column <= 14 * 2^57 + carry < 2^61.  Row sums: 12 limbs of
-// [0, 2^28) < 2^32 (unsigned), the signed top limbs stay small.  Value: |sum| <= 12 * 1 * 2 p^2, result in (-p/64, p + p/64).
-struct c12r_limbs { uint32_t t[2 * FP_N]; };
-BLS_HD void c12r_term(const fp2* A, const fp2* B, int row, int q, c12r_limbs& out) {
-    const int kq = row >> 1, part = row & 1, h = q & 1;
-    const bool live = q < 12;
-    const int i = live ? (q >> 1) : 0;
-    int j = kq - i;
-    const bool wrap = j < 0;
-    if (wrap) j += 6;
-    const fp& x = h ? A[i].c1 : A[i].c0;
-    const fp &b0 = B[j].c0, &b1 = B[j].c1;
-    BLS_REQUIRE(BLS_LB(x) <= 1 && BLS_LB(b0) <= 1 && BLS_LB(b1) <= 1 && BLS_VB(x) <= 2 && BLS_VB(b0) <= 2 && BLS_VB(b1) <= 2, "c12r_term operand bound");
-    // part 0 (real): h 0: B0, h 1: -B1;  part 1 (imaginary): h 0: B1, h 1: B0;  (B0, B1) = wrap ? (b0 - b1, b0 + b1) : (b0, b1)
-    int s0, s1;
-    if (part == 0) { s0 = h ? (wrap ? -1 : 0) : 1; s1 = h ? -1 : (wrap ? -1 : 0); }
-    else           { s0 = h ? 1 : (wrap ? 1 : 0);  s1 = h ? (wrap ? -1 : 0) : 1; }
-    if (!live) { s0 = 0; s1 = 0; }
-    int32_t y[FP_N];
-#pragma unroll
-    for (int l = 0; l < FP_N; l++) y[l] = s0 * (int32_t)b0.l[l] + s1 * (int32_t)b1.l[l];
-    int64_t acc = 0;
-#pragma unroll
-    for (int kk = 0; kk < 2 * FP_N - 1; kk++) {
-#pragma unroll
-        for (int a = (kk < FP_N ? 0 : kk - FP_N + 1); a <= (kk < FP_N ? kk : FP_N - 1); a++) acc = bls_mac(acc, (int32_t)x.l[a], y[kk - a]);
-        out.t[kk] = (uint32_t)acc & FP_MASK;
-        acc >>= 28;
-    }
-    out.t[2 * FP_N - 1] = (uint32_t)acc;
-}
-// Montgomery reduction of a row's limb sums (limbs 0..26 unsigned, limb 27 signed): (sum t_k 2^(28 k)) * 2^-392 mod p, partially reduced
-BLS_HD fp c12r_reduce(const c12r_limbs& s) {
-    int64_t acc = 0;
-    int32_t m[FP_N];
-    fp r;
-#pragma unroll
-    for (int kk = 0; kk < FP_N; kk++) {
-        acc += (int64_t)(uint64_t)s.t[kk];
-#pragma unroll
-        for (int i = 0; i < kk; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
-        m[kk] = (int32_t)(((uint32_t)acc * k::N0) & FP_MASK);
-        acc = bls_mac_c(acc, m[kk], k::P[0]);
-        acc >>= 28;
-    }
-#pragma unroll
-    for (int kk = FP_N; kk < 2 * FP_N - 1; kk++) {
-        acc += (int64_t)(uint64_t)s.t[kk];
-#pragma unroll
-        for (int i = kk - FP_N + 1; i < FP_N; i++) acc = bls_mac_c(acc, m[i], k::P[kk - i]);
-        r.l[kk - FP_N] = (uint32_t)acc & FP_MASK;
-        acc >>= 28;
-    }
-    acc += (int64_t)(int32_t)s.t[2 * FP_N - 1];
-    r.l[FP_N - 1] = (uint32_t)acc;
-    BLS_SET_VB(r, 2);
-    BLS_SET_LB(r, 0);
-    return fp_reduce(r);
-}
-
 }  // namespace bls

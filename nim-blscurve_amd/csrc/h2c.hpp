@@ -234,9 +234,6 @@ struct g2_park_regs {
 // dbl_run: n >= 1 doublings (jac_dbl, or the lane-cooperative jac_dbl_team of a kernel that has a team of lanes per point)
 // add_in: the additions inside the chain (accumulator + parked base); add: the others.  The one-lane-per-point kernels pass the
 // inlined body / the out-of-line addition, the kernels with a team of lanes per point the lane-cooperative jac_add_team.
-#ifndef BLS_CLEAR_MUL
-#define BLS_CLEAR_MUL mul_inplace            // A/B switch: -DBLS_CLEAR_MUL=mul_shared calls the shared multiplier bodies instead
-#endif
 // dbl_run has exactly ONE call site here (the loop over the runs), so that a caller may force it inline: inside a kernel the
 // accumulator is then a plain SSA value.  (Out of line, its loop-carried point lives in the function's return slot, i.e. in scratch
 // memory, and is stored and re-loaded around every doubling all the same.)  dbl1: one doubling, for 2P (not on the hot path).
@@ -311,7 +308,6 @@ BLS_MID jac<F> jac_dbl_n(const jac<F>& a, int n, const M& m) {
     } while (--n > 0);
     return r;
 }
-#if !defined(BLS_CLEAR_DBL_PLAIN)
 // G2 with the bodies in place: the doubling with the lazily reduced Y3 (curve.hpp jac_dbl_lazy)
 BLS_MID jac<fp2> jac_dbl_n(const jac<fp2>& a, int n, const mul_inplace&) {
     jac<fp2> r = a;
@@ -321,7 +317,6 @@ BLS_MID jac<fp2> jac_dbl_n(const jac<fp2>& a, int n, const mul_inplace&) {
     } while (--n > 0);
     return r;
 }
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BLS_LAMBDA_INLINE __attribute__((always_inline))
 #else
@@ -338,7 +333,7 @@ BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return clear_cofactor_g2_with(p, park, mul_shared{});      // the out-of-line form (k_hash_var, the signer): compact code on the shared multipliers
 #else
-    return clear_cofactor_g2_with(p, park, BLS_CLEAR_MUL{});   // host (tests/host_emu, bounds tracker, census): the formulas k_hash_clear runs
+    return clear_cofactor_g2_with(p, park, mul_inplace{});   // host (tests/host_emu, bounds tracker, census): the formulas k_hash_clear runs
 #endif
 }
 

@@ -63,16 +63,11 @@ BLS_MID fp2 fp2_sqr_minus_12sqr(const fp2& a, const fp2& e) {
     const fp e3 = fp_carry(fp_add_nc(fp_dbl_nc(e.c1), e.c1));                           // 3 e1
     return fp2{fp_dot2(fp_add_nc(a.c0, a.c1), fp_sub_nc(a.c0, a.c1), fp_neg(e4s), e3d), fp_dot2(fp_dbl_nc(a.c0), a.c1, fp_neg(e8), e3)};
 }
-// (Round 4 tried the FIRST squaring of a step expanded in place, -DBLS_LINES_FIRST_INL: the 24 line stores of the previous step are in
-// flight when a step begins and a callee opens with s_waitcnt vmcnt(0).  No gain: k_lines' 8 % of non-issuing wave cycles are the 30
-// instruction-fetch restarts of its 15 calls per step and a 43 KB hot loop, not store drains - profiles/r04_ab/ab_lines_first_inline.txt.)
+// (Variants that were measured and dropped - the first squaring of a step expanded in place, the multiplier bodies in place, y3 as
+// two separate squarings, the five addition steps out of line, the flat 63-iteration loop: profiles/r04_ab/ab_lines_*.txt.)
 template <class M>
 BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
-#if defined(BLS_LINES_FIRST_INL)
-    fp2 B = fp2_sqr_inl(t.y);
-#else
     fp2 B = m.sqr(t.y);
-#endif
     fp2 C = m.sqr(t.z);
     fp2 X2 = m.sqr(t.x);
     fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));                       // 4 xi C   (2 -> 4 units, carry, 2)
@@ -81,14 +76,7 @@ BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
     fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.y, t.z)), B), C));           // 2 Y Z
     fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(m.sqr(fp2_add(t.x, t.y)), X2), B));       // 2 X Y = (X + Y)^2 - X^2 - Y^2: a squaring for a product
     fp2 x3 = m.mul(XY2, fp2_carry(fp2_sub_nc(B, F)));
-#if defined(BLS_LINES_Y3_SEPARATE)
-    fp2 E2 = m.sqr(E);
-    fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
-    fp2 S = m.sqr(fp2_carry(fp2_add_nc(B, F)));
-    fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));             // S - 12 E^2
-#else
     fp2 y3 = fp2_sqr_minus_12sqr(fp2_carry(fp2_add_nc(B, F)), E);                       // (B + 3E)^2 - 12 E^2 with two reductions instead of four
-#endif
     fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(m.mul(B, H))));
     t = g2_proj{x3, y3, z3};
     fp2 BE = fp2_sub_nc(B, E);
@@ -184,12 +172,6 @@ BLS_MID line_t miller_add_step_team(g2_proj& t, const g2_proj& q, const g1_pre& 
 
 // Emits the 68 lines of pair (P, Q) through sink(step, line).  A pair with P or Q at infinity
 // contributes 1 (blst skips such pairs in the Miller loop).
-#ifndef BLS_LINES_MUL
-#define BLS_LINES_MUL mul_shared           // A/B switch: who multiplies in the 63 doubling steps of miller_lines
-#endif
-// The five addition steps out of line: they run 5 times in 68 steps, and inlined they make the loop of the 63 doubling steps (with the
-// shared multiplier bodies it calls) larger than the instruction cache serves at full rate (tools/ubench_icache.hip)
-BLS_HDN line_t miller_add_step_ool(g2_proj& t, const g2_proj& q, const g1_pre& p) { return miller_add_step(t, q, p); }
 template <class Sink>
 BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
     bool skip = jac_is_inf(pj) | jac_is_inf(qj);
@@ -198,16 +180,6 @@ BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
     q = g2_proj{fp2_reduce(q.x), fp2_reduce(q.y), fp2_reduce(q.z)};
     g2_proj t = q;
     int s = 0;
-#if defined(BLS_LINES_FLAT)
-    for (int bit = 62; bit >= 0; bit--) {
-        line_t l = miller_dbl_step_m(t, p, BLS_LINES_MUL{});
-        sink(s++, skip ? line_one() : l);
-        if ((k::X_ABS >> bit) & 1) {
-            line_t a = miller_add_step(t, q, p);
-            sink(s++, skip ? line_one() : a);
-        }
-    }
-#else
     // |x| has six set bits: the 63 doubling steps are six RUNS (1, 2, 3, 9, 32, 16) with an addition step behind each but the last.
     // The runs are an inner loop of their own so that the code of the five addition steps (as large as the doubling step's) lies
     // OUTSIDE the loop that executes 63 times: that loop and the shared multiplier bodies it calls are then ~43 KB instead of ~60 KB,
@@ -220,21 +192,16 @@ BLS_HD void miller_lines(const g1_jac& pj, const g2_jac& qj, Sink&& sink) {
         int n = pos - next;
 #pragma clang loop unroll(disable)
         do {
-            line_t l = miller_dbl_step_m(t, p, BLS_LINES_MUL{});
+            line_t l = miller_dbl_step(t, p);
             sink(s++, skip ? line_one() : l);
         } while (--n > 0);
         if (rest) {
-#if defined(BLS_LINES_ADD_OOL)
-            line_t a = miller_add_step_ool(t, q, p);
-#else
             line_t a = miller_add_step(t, q, p);
-#endif
             sink(s++, skip ? line_one() : a);
             rest &= ~(1ull << next);
         }
         pos = next;
     }
-#endif
 }
 
 // f = conj( Horner_s (f^2 [at doubling steps] * L_s) ), L given in miller_lines step order.

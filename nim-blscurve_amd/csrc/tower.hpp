@@ -143,17 +143,6 @@ struct line_ops_lds {
         fp2_lds_put(base + 2 * BLS_LDS_SLOT, l.l2);
         fp2_lds_put(base + 3 * BLS_LDS_SLOT, fp2_add_nc(l.l1, l.l2));
     }
-#if defined(BLS_LINEPROD_INL)
-    // multiplier bodies expanded in place, the line coefficient read from its LDS slot where it is used (no call, no hand-over slot)
-    __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base)); }
-    __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + BLS_LDS_SLOT)); }
-    __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + 2 * BLS_LDS_SLOT)); }
-    __device__ __forceinline__ fp2 mul_m1(const fp2& x) const { return fp2_mul_inl(x, fp2_lds_get(base + 3 * BLS_LDS_SLOT)); }
-    __device__ __forceinline__ fp2 mul_l0l1(const fp2& x) const { return fp2_mul_inl(x, fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT))); }
-    __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const {
-        return fp2_mul_inl(x, fp2_carry(fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + 3 * BLS_LDS_SLOT))));
-    }
-#else
     __device__ __forceinline__ fp2 mul_l0(const fp2& x) const { return fp2_mul_lds(x, base); }
     __device__ __forceinline__ fp2 mul_l1(const fp2& x) const { return fp2_mul_lds(x, base + BLS_LDS_SLOT); }
     __device__ __forceinline__ fp2 mul_l2(const fp2& x) const { return fp2_mul_lds(x, base + 2 * BLS_LDS_SLOT); }
@@ -162,7 +151,6 @@ struct line_ops_lds {
     __device__ __forceinline__ fp2 mul_l0m1(const fp2& x) const {
         return fp2_mul(x, fp2_carry(fp2_add_nc(fp2_lds_get(base), fp2_lds_get(base + 3 * BLS_LDS_SLOT))));
     }
-#endif
 };
 #else
 // host pass of a .hip translation unit: kernels are parsed, never run
@@ -202,11 +190,7 @@ BLS_MID fp12 fp12_mul_by_line_lazy(const fp12& f, const line_t& l) {
     r.c1.a2 = fp2_dot3(b.a2, b.a1, a.a1, l.l0, l.l1, l.l2);
     return r;
 }
-#if defined(BLS_LINEPROD_KARATSUBA)
-BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) { return fp12_mul_by_line_karatsuba(f, l); }
-#else
 BLS_MID fp12 fp12_mul_by_line(const fp12& f, const line_t& l) { return fp12_mul_by_line_lazy(f, l); }
-#endif
 BLS_HD fp12 fp12_reduce(const fp12& a) { return fp12{fp6_reduce(a.c0), fp6_reduce(a.c1)}; }
 
 BLS_HD fp12 fp12_from_line(const line_t& l) {

@@ -154,27 +154,6 @@ unsigned long long emu_mad_census(int stage, const uint8_t* set320, uint64_t r) 
     return 0;
 #endif
 }
-// the row engine (c12r_*): 12 rows x 16 lanes, row sums in a loop here (DPP on the device)
-void emu_c12r_mul(const uint8_t* a576, const uint8_t* b576, uint8_t* out576) {
-    fp12 a = fp12_load_le(a576), b = fp12_load_le(b576), r;
-    fp2 A[6], B[6], D[6];
-    fp2* ta[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
-    fp2* tb[6] = {&b.c0.a0, &b.c0.a1, &b.c0.a2, &b.c1.a0, &b.c1.a1, &b.c1.a2};
-    fp2* tr[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
-    for (int t = 0; t < 6; t++) { A[c12_flat_of_tower(t)] = fp2_reduce(*ta[t]); B[c12_flat_of_tower(t)] = fp2_neg(fp2_reduce(fp2_neg(*tb[t]))); }   // negated limbs on one side: what c12_conj leaves
-    for (int row = 0; row < 12; row++) {
-        c12r_limbs sum{};
-        for (int q = 0; q < 16; q++) {
-            c12r_limbs t;
-            c12r_term(A, B, row, q, t);
-            for (int l = 0; l < 2 * FP_N; l++) sum.t[l] += t.t[l];
-        }
-        fp v = c12r_reduce(sum);
-        if (row & 1) D[row >> 1].c1 = v; else D[row >> 1].c0 = v;
-    }
-    for (int t = 0; t < 6; t++) *tr[t] = D[c12_flat_of_tower(t)];
-    fp12_store_le(out576, r);
-}
 // the lane-cooperative Fp12 engine of k_tail, run item by item (what the lanes do between barriers): schoolbook products (c12s_product), the limb sums of
 // every output coefficient (c12s_limb_sum) and the row reduction (c12_row_reduce_ref: what the device does with DPP row shifts); one operand with negated limbs
 void emu_c12_rowphase(const uint8_t* a576, const uint8_t* b576, int sqr, uint8_t* out576) {

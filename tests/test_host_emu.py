@@ -326,12 +326,8 @@ def test_lane_cooperative_fp12_engine(emu):
         # the engine called with explicit product / square flag (limbs stay in their lanes: carries by neighbour, quotient from lane 13)
         assert fp12_from_bytes(call(emu, "emu_c12_rowphase", A, B, 0, outlen=576)) == o.f12mul(a, b)
         assert fp12_from_bytes(call(emu, "emu_c12_rowphase", A, A, 1, outlen=576)) == o.f12sqr(a)
-        # the row engine (one 16-lane row per output coefficient, one reduction per row)
-        assert fp12_from_bytes(call(emu, "emu_c12r_mul", A, B, outlen=576)) == o.f12mul(a, b)
-        assert fp12_from_bytes(call(emu, "emu_c12r_mul", A, A, outlen=576)) == o.f12sqr(a)
-    # extreme operands: p - 1 in every coefficient (largest canonical limbs and values), and a chain on the row engine
+    # extreme operands: p - 1 in every coefficient (largest canonical limbs and values)
     top = fp12_to_bytes(tuple((o.P - 1, o.P - 1) for _ in range(6)))
-    assert fp12_from_bytes(call(emu, "emu_c12r_mul", top, top, outlen=576)) == o.f12sqr(fp12_from_bytes(top))
     x = fp12_to_bytes(rnd12())
     want = fp12_from_bytes(x)
     for i in range(8):                                   # a chain on the row phase: semi-normalised limbs feed the next product
@@ -339,12 +335,6 @@ def test_lane_cooperative_fp12_engine(emu):
         want = o.f12sqr(want)
     assert fp12_from_bytes(x) == want
     assert fp12_from_bytes(call(emu, "emu_c12_rowphase", top, top, 1, outlen=576)) == o.f12sqr(fp12_from_bytes(top))
-    x = fp12_to_bytes(rnd12())
-    want = fp12_from_bytes(x)
-    for i in range(6):
-        x = call(emu, "emu_c12r_mul", x, x, outlen=576)
-        want = o.f12sqr(want)
-    assert fp12_from_bytes(x) == want
     x = fp12_to_bytes(rnd12())
     want = fp12_from_bytes(x)
     for i in range(6):

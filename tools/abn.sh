@@ -1,9 +1,9 @@
 # Same-box A/B/N of prebuilt libraries nim-blscurve_amd/variants/<name>.so (box-to-box variance is a few percent, so
 # optimisations are judged on one box, interleaved).  usage (on the GPU box): [WHAT=bench|msm|lat] bash tools/abn.sh ROUNDS name1 name2 ...
 R=$GRAFT_REPO_ROOT; rounds=$1; shift
-cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so
+# a variant is selected with MI355_BLS_LIB (nim-blscurve_amd/__init__.py): the shipped library is never overwritten
 for r in $(seq $rounds); do for v in "$@"; do
-  cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so; touch $R/nim-blscurve_amd/libblscurve_mi355x.so
+  export MI355_BLS_LIB=$R/nim-blscurve_amd/variants/$v.so
   echo -n "$v "
   case "${WHAT:-bench}" in
     msm) timeout 300 python3 $R/tests/gpu_probe_aux.py msm 2>/dev/null | tail -2 | tr '\n' ' '; echo ;;
@@ -12,4 +12,4 @@ for r in $(seq $rounds); do for v in "$@"; do
 import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), round(d['ms_one_caller'],2), {k:round(v,3) for k,v in d['kernel_ms_alone'].items()}, {k:round(v,3) for k,v in d.get('tail_ms_alone',{}).items()})" ;;
   esac
 done; done
-cp /tmp/keep.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+unset MI355_BLS_LIB

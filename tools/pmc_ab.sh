@@ -1,16 +1,16 @@
 # SQ / instruction-cache counters of prebuilt variants nim-blscurve_amd/variants/<name>.so, one caller (kernels alone), per kernel and launch.
 # usage (GPU box): bash tools/pmc_ab.sh OUTDIR name1 name2 ...      -> OUTDIR/<name>.json + a table on stdout
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so
+# a variant is selected with MI355_BLS_LIB (nim-blscurve_amd/__init__.py): the shipped library is never overwritten
 P="$R/bench.py --no-cpu --no-aux --no-one-caller --steps 2 --warmup 1 --inflight 1 --ctx-mode throughput"
 for v in "$@"; do
-  cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so; touch $R/nim-blscurve_amd/libblscurve_mi355x.so
+  export MI355_BLS_LIB=$R/nim-blscurve_amd/variants/$v.so
   rm -rf /tmp/pmc_$v; mkdir -p /tmp/pmc_$v
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH --output-format csv -d /tmp/pmc_$v/a -o p -- python3 $P > /tmp/pmc_$v/a.log 2>&1
   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_IFETCH_LEVEL GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_$v/b -o p -- python3 $P > /tmp/pmc_$v/b.log 2>&1
   python3 $R/tools/summarize_pmc.py $O/$v.json /tmp/pmc_$v/a /tmp/pmc_$v/b > /dev/null 2>&1
 done
-cp /tmp/keep.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+unset MI355_BLS_LIB
 python3 - "$O" "$@" <<'PY'
 import json, sys
 o, names = sys.argv[1], sys.argv[2:]

@@ -2,9 +2,9 @@
 # plus the launch-by-launch list of k_tail durations (tests/gpu_probe_aux.py fav b4096)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so
+# a variant is selected with MI355_BLS_LIB (nim-blscurve_amd/__init__.py): the shipped library is never overwritten
 for v in ${VARS:-g1dot rowe}; do
-  cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so; touch $R/nim-blscurve_amd/libblscurve_mi355x.so
+  export MI355_BLS_LIB=$R/nim-blscurve_amd/variants/$v.so
   rm -rf /tmp/pt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- python3 $R/tests/gpu_probe_aux.py fav b4096 > /tmp/l.log 2>&1
   echo "== $v"; python3 - <<'PY'
 import csv,glob
@@ -17,4 +17,4 @@ f2=glob.glob('/tmp/pt/**/*kernel_trace.csv',recursive=True)[0]
 print([round((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6,3) for r in csv.DictReader(open(f2)) if 'k_tail' in r['Kernel_Name']])
 PY
 done
-cp /tmp/keep.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+unset MI355_BLS_LIB

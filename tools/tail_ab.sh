@@ -1,8 +1,8 @@
 # k_tail / k_fold average durations (rocprofv3 --kernel-trace --stats of tests/gpu_probe_lat.py) for prebuilt variants/<name>.so
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-cp $R/nim-blscurve_amd/libblscurve_mi355x.so /tmp/keep.so
+# a variant is selected with MI355_BLS_LIB (nim-blscurve_amd/__init__.py): the shipped library is never overwritten
 for v in "$@"; do
-  cp $R/nim-blscurve_amd/variants/$v.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+  export MI355_BLS_LIB=$R/nim-blscurve_amd/variants/$v.so
   rm -rf /tmp/kt_$v
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$v -o t -- python3 $R/tests/gpu_probe_lat.py > /dev/null 2>&1
   python3 - <<PY
@@ -16,4 +16,4 @@ for r in csv.DictReader(open(f)):
 print("$v:", "; ".join(out))
 PY
 done
-cp /tmp/keep.so $R/nim-blscurve_amd/libblscurve_mi355x.so
+unset MI355_BLS_LIB
