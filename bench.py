@@ -58,6 +58,8 @@ MAD_CEILING = 30.39e12          # the committed figure; the run measures it agai
 # algorithmic HBM bytes per tuple of the WHOLE path, SURVEY.md section 8(d): one 320-byte SignatureSet read per verification
 PATH_BYTES_PER_TUPLE = 320
 # the fixed per-kernel table of the roofline object (the wide kernels of one batch, in pipeline order)
+# one blocking batchVerify at these sizes, GPU and CPU (benchmarks/bench_all.nim:48-65 uses 6 / 60 / 180; 65 536 is the headline batch)
+LATENCY_CURVE_SIZES = (1, 6, 60, 180, 512, 1024, 4096, 16384, 65536)
 ROOFLINE_KERNELS = ("k_hash_map", "k_hash_clear", "k_pkmul", "k_sig_bucket", "k_lines", "k_lineprod")
 # which stage timer (HIP events inside the library) measures which single kernel
 KERNEL_OF_STAGE = {"pk_mul": "k_pkmul", "miller_lines": "k_lines"}
@@ -619,6 +621,8 @@ def main():
             import c_oracle as co      # the CPU restatement: this leg only
             out["cpu_baseline"] = cpu_baseline(co, a.cpu_sample, rnd)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            if "aux" in out and "latency_curve" in out["aux"]:
+                out["crossover"] = crossover(out["aux"]["latency_curve"], out["cpu_baseline"])
         print(json.dumps(out), flush=True)
     if sharded_path:
         dist.barrier()
@@ -856,6 +860,25 @@ def aux_rows(m, cache, dev):
     oks, _ = m.signSets_device(cache, sk_t.data_ptr(), ms_t.data_ptr(), 65536, o_t.data_ptr())
     out["batch_signer_65536"] = {"ms_per_call": (time.perf_counter() - t0) * 1e3}
     assert oks
+    # Latency curve: ONE blocking batchVerify per size, the sizes of the reference's own benchmark (benchmarks/bench_all.nim:48-65: batches of
+    # 6 / 60 / 180 signatures) up to the headline batch, each on a context of its own size (latency mode, the default stream).  The CPU leg
+    # (cpu_baseline.latency_curve) times the same sizes on all host cores; main() joins the two and names the crossover.
+    dcurve = sign_records(m, cache, dev, range(1 << 23, (1 << 23) + 65536))
+    curve = []
+    for ncv in LATENCY_CURVE_SIZES:
+        cc = m.BatchedBLSVerifierCache.init(max_sets=max(ncv, 1), device=dev.index or 0)
+        for _ in range(2):
+            assert cc.verify_device(dcurve.data_ptr(), ncv, rnd, 0)
+        reps = 8 if ncv <= 4096 else 4
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            assert cc.verify_device(dcurve.data_ptr(), ncv, rnd, 0)
+        dtc = (time.perf_counter() - t0) / reps
+        curve.append({"n": ncv, "ms_per_blocking_call": round(dtc * 1e3, 4), "verifications_per_s": round(ncv / dtc, 1)})
+        cc.close()
+    out["latency_curve"] = curve
+    del dcurve
     # a 64-set batch (the size of one beacon block's signature sets): latency
     d64 = sign_records(m, cache, dev, range(64))
     c64 = m.BatchedBLSVerifierCache.init(max_sets=64, device=dev.index or 0)
@@ -948,6 +971,35 @@ def aux_rows(m, cache, dev):
                           "GBs_at_128B_per_point": 128.0 * nm / dt / 1e9, "hbm_frac_at_128B_per_point": 128.0 * nm / dt / 1e9 / HBM_PEAK_GBS,
                           "stage_ms": {"sort": tm["blinding"], "buckets": tm["hash_to_g2"], "segments": tm["pk_mul"], "windows": tm["sig_mul_sum"]}}
     return out
+
+
+# What one BLST core does per signature inside a batch verification, for the crossover ESTIMATE against the real reference (no BLST on the
+# box): the reference's README quotes about 1 ms for a single verification and roughly a third of that per signature in a batch (shared
+# final exponentiation, N_MAX = 8 Miller batches) on a modern x86 core; the C restatement measured here is several times slower than that.
+BLST_US_PER_SIG_IN_BATCH = 400.0
+BLST_US_FIXED = 600.0
+
+
+def crossover(gpu_curve, cpu):
+    """Joins the GPU latency curve with the CPU one: per size the blocking-call time of each, the smallest size from which the GPU call is
+    faster than (a) the C restatement on this box's cores (MEASURED) and (b) a BLST model on the same number of cores (ESTIMATE:
+    BLST_US_FIXED + n * BLST_US_PER_SIG_IN_BATCH / min(n, cores); BLST itself is not on the box)."""
+    cores = cpu.get("cores", 1)
+    ccurve = {r["n"]: r for r in cpu.get("latency_curve", [])}
+    rows, n_port, n_blst = [], None, None
+    for g in gpu_curve:
+        n = g["n"]
+        blst_ms = (BLST_US_FIXED + n * BLST_US_PER_SIG_IN_BATCH / max(1, min(n, cores))) / 1e3
+        row = {"n": n, "gpu_ms": g["ms_per_blocking_call"], "cpu_port_ms": ccurve.get(n, {}).get("ms_per_call"), "blst_model_ms": round(blst_ms, 3)}
+        rows.append(row)
+    for r in rows:                                   # the first size from which the GPU stays ahead
+        if n_port is None and r["cpu_port_ms"] is not None and all(q["gpu_ms"] < q["cpu_port_ms"] for q in rows if q["n"] >= r["n"] and q["cpu_port_ms"] is not None):
+            n_port = r["n"]
+        if n_blst is None and all(q["gpu_ms"] < q["blst_model_ms"] for q in rows if q["n"] >= r["n"]):
+            n_blst = r["n"]
+    return {"rows": rows, "cores": cores, "gpu_faster_than_cpu_port_from_n": n_port, "gpu_faster_than_blst_model_from_n": n_blst,
+            "blst_model": "ESTIMATE, not a measurement: %.0f us + n x %.0f us / min(n, cores) - BLST is not installed on the box" % (BLST_US_FIXED, BLST_US_PER_SIG_IN_BATCH),
+            "note": "one blocking batchVerify per size on each side; below the crossover a host should keep its CPU path (INTEGRATION.md, 'When to call the GPU')"}
 
 
 def host_cores():
@@ -1062,6 +1114,25 @@ def cpu_baseline(co, sample, rnd):
            "host": {"sched_affinity_cpus": aff, "cgroup_cpu_quota": quota, "threads_used": use},
            "sample": "%d tuples of the same workload, batchVerifyParallel shape with %d threads, %.1f s (oracle/bls_oracle.c: plain-C restatement of "
                      "the reference algorithm, not BLST; BLST's assembly is several times faster per core)" % (sample, use, dt)}
+    # the same sizes as aux.latency_curve, one blocking call each on min(n, cores) threads (the reference's B = min(n, numThreads)); the
+    # headline size is the main leg above
+    ccurve = []
+    for ncv in LATENCY_CURVE_SIZES:
+        if ncv > 16384:
+            ccurve.append({"n": ncv, "ms_per_call": round(ncv / (sample / dt) * 1e3, 3), "verifications_per_s": round(sample / dt, 1), "threads": use, "from": "the main leg's rate"})
+            continue
+        tcv = max(1, min(ncv, use))
+        co.set_num_threads(tcv)
+        rcv = (recs * ((ncv + sample - 1) // sample))[:320 * ncv] if ncv > sample else recs[:320 * ncv]
+        reps = 3 if ncv <= 1024 else 1
+        assert co.batch_verify(rcv, rnd, tcv)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            assert co.batch_verify(rcv, rnd, tcv)
+        dcv = (time.perf_counter() - t0) / reps
+        ccurve.append({"n": ncv, "ms_per_call": round(dcv * 1e3, 3), "verifications_per_s": round(ncv / dcv, 1), "threads": tcv})
+    co.set_num_threads(use)
+    out["latency_curve"] = ccurve
     blst = blst_baseline(recs[:320 * min(sample, 16384)], rnd, use)
     out["blst_on_this_box"] = blst is not None
     if blst is not None:

@@ -629,6 +629,17 @@ __global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P
 }
 
 // lines[s] : 6 fp planes (l0.c0,l0.c1,l1.c0,l1.c1,l2.c0,l2.c1), step-major
+// Round 5: the 68-step walk is ONE hand-allocated assembly statement (tools/gen_lines_asm.py -> build/lines_asm.inc; formulas, carries and
+// reductions of pairing.hpp's miller_dbl_step / miller_add_step, executed and checked lane-for-lane by tests/test_asm_loops.py): T, B and E in
+// fixed VGPR blocks, Q and the P-side factors in AGPRs, four multiplier subroutines that read fixed operand slots, the 24 line stores of a
+// step issued from the result registers and never waited for.  The compiled prologue (P-side factors, Q in homogeneous form) hands its
+// ten Fp values over through five LDS slots.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LINES_NOASM)
+#include "../build/lines_asm.inc"
+__device__ __forceinline__ void lines_asm(uint4* lines, uint32_t stride16, uint32_t off16, uint32_t skip, uint32_t lds_a, uint32_t lds_b) {
+    asm volatile(BLS_LINES_ASM_BODY : : "s"(lines), "s"(stride16), "v"(off16), "v"(skip), "s"(lds_a), "s"(lds_b) : BLS_LINES_ASM_CLOBBERS);
+}
+#endif
 __global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
                                                 uint4* __restrict__ lines) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,6 +647,31 @@ __global__ void __launch_bounds__(WAVE) k_lines(const uint4* __restrict__ P, con
     i += first;
     g1_jac p = soa_ld_g1(P, stride, i);
     g2_jac q = soa_ld_g2(H, stride, i);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LINES_NOASM)
+    if (stride * 16 * 24 < ((size_t)1 << 32)) {      // wave-uniform: the loop's row arithmetic is 32-bit (24 rows of a step < 4 GiB: up to 11 M pairs per context)
+        __shared__ bls_u32x4 hand_over[4 * BLS_LDS_SLOT];
+        const bool skip = jac_is_inf(p) | jac_is_inf(q);
+        if (skip) {                                    // a pair with P or Q at infinity contributes 1 (blst skips it): rare, stored here; the loop stores nothing for the lane
+            const line_t one = line_one();
+            for (int s = 0; s < N_LINES; s++) {
+                uint4* b = lines + (size_t)s * 24 * stride;
+                soa_st2(b, stride, 0, i, one.l0);
+                soa_st2(b, stride, 2, i, one.l1);
+                soa_st2(b, stride, 4, i, one.l2);
+            }
+        }
+        const g1_pre pre = g1_precompute(p);
+        g2_proj t = g2_to_proj(q);
+        bls_lds_u32x4* ho = (bls_lds_u32x4*)hand_over;
+        fp2_lds_put(ho, fp2_reduce(t.x));
+        fp2_lds_put(ho + BLS_LDS_SLOT, fp2_reduce(t.y));
+        fp2_lds_put(ho + 2 * BLS_LDS_SLOT, fp2_reduce(t.z));
+        fp2_lds_put(ho + 3 * BLS_LDS_SLOT, fp2{pre.z3, pre.nxz3});
+        fp2_lds_put((bls_lds_u32x4*)bls_xchg, fp2{pre.xz, pre.y});       // the multipliers' hand-over slot is free now: every product above is done
+        lines_asm(lines, (uint32_t)(stride * 16), i * 16u, skip ? 1u : 0u, (uint32_t)(uintptr_t)ho, (uint32_t)(uintptr_t)(bls_lds_u32x4*)bls_xchg);
+        return;                                        // nothing may follow the statement: it leaves m0 / scc / the registers it names clobbered
+    }
+#endif
     miller_lines(p, q, [&](int s, const line_t& l) {
         uint4* b = lines + (size_t)s * 24 * stride;
         soa_st2(b, stride, 0, i, l.l0);

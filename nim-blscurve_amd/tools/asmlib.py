@@ -250,6 +250,8 @@ class Builder:
         return d.like(x.vb, _u(x.lb))
 
     def mov(self, d, x):
+        if d.r == x.r and d.agpr == x.agpr:
+            return d.like(x.vb, x.lb)
         for i in range(NL):
             if d.agpr and not x.agpr:
                 self.a.e("awrite", d.r[i], x.r[i])
