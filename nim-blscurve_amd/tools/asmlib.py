@@ -294,10 +294,10 @@ class Builder:
         return d.like(x.vb, 1)
 
     def reduce(self, d, x, scale=1):
-        """fp_reduce of scale * x (scale: a small positive integer folded into the chain as a multiplier - no limb-wise multiple,
-        no carry step in front): subtracts round(scale x / p) p, estimated from the top limbs; |result| < 0.51 p, canonical limbs.
+        """fp_reduce of scale * x (scale: a small integer, an inline constant -16 .. 64, folded into the chain as a multiplier - no
+        limb-wise multiple, no carry step in front, and a negative one gives the negated value for free): subtracts round(scale x / p) p, estimated from the top limbs; |result| < 0.51 p, canonical limbs.
         d may be x."""
-        assert x.vb * scale <= 1024 and _u(x.lb) * scale <= 56, "reduce bound"
+        assert -16 <= scale <= 64 and scale != 0 and x.vb * abs(scale) <= 1024 and _u(x.lb) * abs(scale) <= 56, "reduce bound"
         a, t, t2 = self.a, self.tmp, self.tmp2
         a.e("ashr", t, x.r[NL - 2], 28)
         a.e("add", t, x.r[NL - 1], t)                          # top = a13 + (a12 >> 28)

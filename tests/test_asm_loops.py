@@ -1,0 +1,76 @@
+"""The generated hand-allocated assembly loops built on nim-blscurve_amd/tools/asmlib.py (round 5): asmlib's one-lane interpreter executes
+the SAME instruction tuples that become the kernel's text and checks every step against big-integer arithmetic - coordinates of the walking
+point, the three line coefficients, the declared limb and value bounds of every stored value - with the field operations' preconditions
+(fp.hpp's worst-case bookkeeping) asserted while generating.  No GPU needed; the GPU parity tests cover the assembled kernels."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(ROOT, "nim-blscurve_amd", "tools")
+
+
+def run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(TOOLS, script)] + list(args), capture_output=True, text=True, cwd=TOOLS)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_lines_loop_whole_walk_matches_bigint_model():
+    """k_lines: single doubling / addition steps and the whole 68-step walk (63 doublings, 5 additions, 204 line coefficients)."""
+    out = run("gen_lines_asm.py", "--selftest")
+    assert "selftest ok" in out
+    m = re.search(r"doubling step (\d+) VALU instructions \((\d+) multiply-adds", out)
+    valu, mads = int(m.group(1)), int(m.group(2))
+    # 9 800 operand / reduction multiply-adds of the step's 22 Montgomery reductions (pairing.hpp's census) + 60 of the two scaled partial reductions
+    assert mads == 9860
+    assert valu <= 13100, "the doubling step grew: %d instructions" % valu
+
+
+def test_lines_text_is_one_statement():
+    t = run("gen_lines_asm.py")
+    assert "#define BLS_LINES_ASM_BODY" in t and "#define BLS_LINES_ASM_CLOBBERS" in t
+    assert "scratch_" not in t and "s_waitcnt vmcnt" not in t      # no spills; the line stores are never waited for
+    assert t.count("s_setpc_b64") == 4                             # four multiplier subroutines
+    assert '"v249"' in t and '"v250"' not in t and '"a255"' in t
+    # every store of a line coefficient goes through the running row pointer with the lane's 32-bit byte offset
+    assert t.count("global_store_dwordx4") == 2 * 3 * 2 * 3 and t.count("global_store_dwordx2") == 2 * 3 * 2
+
+
+def test_asmlib_reduce_and_carry_against_bigints():
+    """the two normalisation steps of asmlib.Builder on extreme inputs: fp_carry_step and fp_reduce with a folded scale"""
+    sys.path.insert(0, TOOLS)
+    import random
+    import asmlib as al
+    a = al.Asm(100, 36, 50, 51, 52)
+    b = al.Builder(a, list(range(84, 98)), 110, 111)
+    x, d = al.blk(0), al.blk(14)
+    rnd = random.Random(5)
+    for scale in (1, 3, 12, -16):
+        for trial in range(40):
+            a.ins = []
+            vb = 1024 // abs(scale) if trial % 2 else 2
+            val = rnd.randrange(-vb * al.P, vb * al.P)
+            # limbs: canonical ones shifted around by up to the allowed units (carry-less sums)
+            ls = al.limbs_of(val % (1 << 392)) if val >= 0 else None
+            if ls is None:
+                ls = [(-l) & 0xffffffff for l in al.limbs_of((-val) % (1 << 392))]
+            mach = al.Machine(a)
+            al.put(mach, x, ls)
+            assert al.get(mach, x) == val
+            r = b.reduce(d, x.like(vb, 1), scale)
+            mach.run(a.ins)
+            got = al.get(mach, d)
+            assert (got - scale * val) % al.P == 0 and abs(got) < 0.51 * al.P, (scale, val, got)
+            al.check_limbs(mach, d, 0)
+    for trial in range(40):
+        a.ins = []
+        ls = [rnd.randrange(-(7 << 28), 7 << 28) & 0xffffffff for _ in range(al.NL)]
+        mach = al.Machine(a)
+        al.put(mach, x, ls)
+        val = al.get(mach, x)
+        b.carry(x, x.like(4, 7))
+        mach.run(a.ins)
+        assert al.get(mach, x) == val
+        al.check_limbs(mach, x, 1)
