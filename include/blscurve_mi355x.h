@@ -381,6 +381,11 @@ int mi355_bls_last_timings(mi355_bls_ctx* ctx, float out[8]);
  * k_lineprod, k_lineprod2 (line_products). */
 int mi355_bls_last_kernel_timings(mi355_bls_ctx* ctx, float out[4]);
 
+/* TEST HOOK: out[i] = clear_cofactor(q0_i + q1_i) (RFC 9380 G.3, the last stage of hash-to-G2) for n <= max_sets pairs of blst_p2 images
+ * (2 x 288 B per pair, host memory), computed by k_hash_clear itself - lets the tests put points through the kernel that no hash produces
+ * (the point at infinity, equal or opposite points: the cases its incomplete addition formulas flag and recompute). */
+int mi355_bls_debug_g2_clear_cofactor(mi355_bls_ctx* ctx, const uint8_t* in_pairs, size_t n, uint8_t* out_p2);
+
 /* Test hooks (no reference counterpart).  debug_fail_next_enqueue: the next batch / shard enqueue on this context fails with
  * MI355_BLS_ERR_HIP before touching the device (exercises the multi-device driver's clean-up path).  debug_multi_enqueue_us:
  * host time in microseconds, counted from the start of the last mi355_bls_batch_verify_multi* call of this thread, at which each

@@ -305,6 +305,41 @@ BLS_HDN jac<F> jac_add_impl(const jac<F>& p, const jac<F>& q) { return jac_add_b
 template <class F>
 BLS_HD jac<F> jac_add(jac<F> p, jac<F> q) { return jac_add_impl(p, q); }
 
+// acc + base for a base that is added again and again (the doubling chains of the cofactor clearing add the same point five times per
+// chain): Z2^2 and Z2^3 are computed once (jac_precompute), so an addition is 3 squarings + 11 products instead of 4 + 12.  NOT complete:
+// an operand at infinity or P == +-Q all give Z3 = 0 (Z3 = Z1 Z2 H) with X3, Y3 meaningless - the caller tests Z3 after every addition
+// (and the base's Z once) and recomputes with the complete formulas if it ever is zero.  These are the formulas of the assembly loop of
+// k_hash_clear (tools/gen_clear_asm.py); the host test build runs them under the bounds tracker.
+template <class F>
+struct jac_pre {
+    jac<F> p;
+    F zz, zzz;
+};
+template <class F>
+BLS_MID jac_pre<F> jac_precompute(const jac<F>& q) {
+    F zz = f_sqr(q.z);
+    return jac_pre<F>{q, zz, f_mul(q.z, zz)};
+}
+template <class F>
+BLS_MID jac<F> jac_add_pre(const jac<F>& p, const jac_pre<F>& q) {
+    F Z1Z1 = f_sqr(p.z);
+    F U2 = f_mul(q.p.x, Z1Z1);
+    F S2 = f_mul(f_mul(q.p.y, p.z), Z1Z1);
+    F Z12 = f_mul(p.z, q.p.z);
+    F U1 = f_mul(p.x, q.zz);
+    F H = f_sub(U2, U1);
+    F S1 = f_mul(p.y, q.zzz);
+    F rr = f_sub(S2, S1);
+    jac<F> r;
+    r.z = f_mul(Z12, H);
+    F HH = f_sqr(H);
+    F HHH = f_mul(H, HH);
+    F V = f_mul(U1, HH);
+    r.x = f_red(f_sub_nc(f_sub_nc(f_sqr(rr), HHH), f_dbl_nc(V)));
+    r.y = f_carry(f_sub_nc(f_mul(rr, f_sub_nc(V, r.x)), f_mul(S1, HHH)));
+    return r;
+}
+
 // Lane-cooperative complete addition (the formulas, carries and reductions of jac_add_body; products by the Team): five rounds
 //   Z1^2, Z2^2  |  X1 Z2Z2, X2 Z1Z1, Y1 Z2, Y2 Z1  |  (Y1 Z2) Z2Z2, (Y2 Z1) Z1Z1, Z1 Z2, H^2  |  H HH, U1 HH, (Z1 Z2) H, r^2  |  r (V - X3), S1 HHH
 // instead of sixteen multiplications in a row on every lane.  P == Q falls through to the team doubling.

@@ -317,6 +317,50 @@ BLS_MID jac<fp2> jac_dbl_n(const jac<fp2>& a, int n, const mul_inplace&) {
     } while (--n > 0);
     return r;
 }
+// Round 5: the chain acc = [|x|] base as ONE unit (k_hash_clear runs it as a hand-allocated assembly loop, tools/gen_clear_asm.py) and the
+// clearing around it: `chain(base)` returns [|x|] base, everything else (psi maps, the six additions outside the chains, the one plain
+// doubling) stays with the caller's complete formulas.
+template <class Pt, class Chain, class Dbl1, class Add>
+BLS_MID Pt clear_cofactor_g2_chain(const Pt& p, Chain&& chain, Dbl1&& dbl1, Add&& add) {
+    Pt base = p, u = p, res = p;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < 2; pass++) {
+        Pt acc = jac_neg(chain(base));                                   // [x] base (x < 0); the one call site of the chain
+        if (pass == 0) {
+            Pt t2 = g2_psi(p);
+            u = add(g2_psi(g2_psi(dbl1(p))), jac_neg(t2));               // psi^2(2P) - psi(P)
+            u = add(u, jac_neg(acc));                                    // - [x]P
+            u = add(u, jac_neg(p));                                      // - P
+            base = add(acc, t2);                                         // [x]P + psi(P)
+        } else {
+            res = add(u, acc);
+        }
+    }
+    return res;
+}
+// What the chain computes, in the formulas of the assembly loop: the base normalised (partial reductions), its Z^2 and Z^3 once, 63 doublings
+// (jac_dbl_lazy) and 5 incomplete additions (jac_add_pre); ok = false when a Z turned out zero on the way (an operand at infinity, P == +-Q):
+// the result is then meaningless and the caller recomputes with complete formulas.  Host test build: bounds tracker + multiply-add census.
+BLS_MID g2_jac g2_chain_x_fast(const g2_jac& b0, bool& ok) {
+    const g2_jac base{fp2_reduce(b0.x), fp2_reduce(b0.y), fp2_reduce(b0.z)};
+    ok = !fp2_is_zero(base.z);
+    const jac_pre<fp2> pre = jac_precompute(base);
+    g2_jac acc = base;
+#pragma clang loop unroll(disable)
+    for (int i = 62; i >= 0; i--) {
+        acc = jac_dbl_lazy(acc);
+        if ((k::X_ABS >> i) & 1) {
+            acc = jac_add_pre(acc, pre);
+            ok = ok & !fp2_is_zero(acc.z);
+        }
+    }
+    return acc;
+}
+BLS_HD g2_jac g2_chain_x(const g2_jac& base) {
+    bool ok;
+    g2_jac r = g2_chain_x_fast(base, ok);
+    return ok ? r : jac_mul_u64_jac(base, k::X_ABS);
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BLS_LAMBDA_INLINE __attribute__((always_inline))
 #else
@@ -333,7 +377,9 @@ BLS_HDN g2_jac clear_cofactor_g2(const g2_jac& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return clear_cofactor_g2_with(p, park, mul_shared{});      // the out-of-line form (k_hash_var, the signer): compact code on the shared multipliers
 #else
-    return clear_cofactor_g2_with(p, park, mul_inplace{});   // host (tests/host_emu, bounds tracker, census): the formulas k_hash_clear runs
+    (void)park;
+    return clear_cofactor_g2_chain(p, [](const g2_jac& b) { return g2_chain_x(b); }, [](const g2_jac& a) { return jac_dbl(a); },
+                                   [](const g2_jac& a, const g2_jac& b) { return jac_add(a, b); });   // host (tests/host_emu, bounds tracker, census): the formulas k_hash_clear runs
 #endif
 }
 

@@ -352,17 +352,50 @@ struct g2_park_lds {
     __device__ __forceinline__ g2_jac get() const { return g2_jac{fp2_lds_get(base), fp2_lds_get(base + BLS_LDS_SLOT), fp2_lds_get(base + 2 * BLS_LDS_SLOT)}; }
 };
 #endif
-__global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+// Round 5: the WHOLE kernel body is one hand-allocated assembly statement (tools/gen_clear_asm.py -> build/clear_asm.inc; curve.hpp's
+// jac_dbl_lazy / jac_precompute + jac_add_pre / g2_psi in h2c.hpp's clear_cofactor_g2_chain order, executed and checked end to end by
+// tests/test_asm_loops.py): loads of the two mapped points, P = q0 + q1, both doubling chains, the psi maps, the seven additions around them,
+// the store.  (Moving only the chains into assembly gained nothing - the compiled chain already ran at 4.2 cycles per instruction; the seven
+// out-of-line complete additions around it ran at 7.3, their 252 argument words each travelling through scratch memory: 11 % of the
+// instructions, 17 % of the time.)  Points that outlive a chain wait in three LDS slots and in two columns per lane of `scratch` (the
+// context's line store, unused until k_lines; other streams only touch columns >= n of it).  A lane that met an exceptional case of the
+// incomplete addition formulas (a Z that turned out zero: operand at infinity, P == +-Q) comes back flagged and is recomputed here with the
+// complete compiled formulas - never taken for hash outputs, exercised by mi355_bls_debug_g2_clear_cofactor.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_CLEAR_NOASM)
+#include "../build/clear_asm.inc"
+__device__ __forceinline__ uint32_t clear_asm(const uint4* M, uint32_t mstride16, uint4* H, uint32_t stride16, uint4* scratch, uint32_t sstride16, uint32_t i, uint32_t lds) {
+    uint32_t flag;
+    asm volatile(BLS_CLEAR_ASM_BODY : "=v"(flag) : "s"(M), "s"(mstride16), "s"(H), "s"(stride16), "s"(scratch), "s"(sstride16), "v"(i), "s"(lds) : BLS_CLEAR_ASM_CLOBBERS);
+    return flag;
+}
+#endif
+__global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride, uint4* __restrict__ scratch) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 park_slots[3 * BLS_LDS_SLOT];
     g2_park_lds park{(bls_lds_u32x4*)park_slots};
 #else
     g2_park_regs park;               // host pass of the translation unit: kernels are parsed, never run
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_CLEAR_NOASM)
+    if (scratch && mstride * 16 * 24 < ((size_t)1 << 32) && stride * 16 * 24 < ((size_t)1 << 32)) {      // wave-uniform: the loop's row arithmetic is 32-bit
+        const uint32_t flag = clear_asm(M, (uint32_t)(mstride * 16), H, (uint32_t)(stride * 16), scratch, (uint32_t)(stride * 16), i, (uint32_t)(uintptr_t)park.base);
+        if (flag) {                     // complete formulas for this lane (the out-of-line compact form)
+            g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
+            soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
+        }
+        return;
+    }
+#endif
+    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
     soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park, mul_inplace{}));
+}
+// test entry (mi355_bls_debug_g2_clear_cofactor): pairs of blst_p2 images -> the SoA layout k_hash_map leaves its mapped points in
+__global__ void __launch_bounds__(WAVE) k_debug_to_soa(const uint32_t* __restrict__ in, uint32_t npoints, uint4* __restrict__ M, size_t mstride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    soa_st_g2(M, mstride, i, ld_g2_blst(in + (size_t)i * 72));
 }
 
 // arbitrary-length message (fastAggregateVerify / coreVerify shape): ONE message, so latency is all that matters.

@@ -102,6 +102,10 @@ class Asm:
             return "v_lshl_add_u32 v%d, v%d, %d, v%d" % (t[1], t[2], t[3], t[4])
         if op == "ashr":
             return "v_ashrrev_i32_e64 v%d, %d, v%d" % (t[1], t[3], t[2])
+        if op == "or3":
+            return "v_or3_b32 v%d, v%d, v%d, v%d" % (t[1], t[2], t[3], t[4])
+        if op == "flag0":                                      # d = 1 where t == 0 (two instructions)
+            return "v_cmp_eq_u32_e64 vcc, 0, v%d\nv_cndmask_b32_e64 v%d, v%d, 1, vcc" % (t[2], t[1], t[1])
         if op == "awrite":
             return "v_accvgpr_write_b32 a%d, v%d" % (t[1], t[2])
         if op == "aread":
@@ -113,7 +117,11 @@ class Asm:
         raise ValueError(op)
 
     def text(self):
-        return [self.text_of(t) for t in self.ins if t[0] != "hook"]
+        out = []
+        for t in self.ins:
+            if t[0] != "hook":
+                out += self.text_of(t).split("\n")
+        return out
 
 
 class Machine:
@@ -178,6 +186,12 @@ class Machine:
                 v[t[1]] = ((v[t[2]] << t[3]) + v[t[4]]) & 0xffffffff
             elif op == "ashr":
                 v[t[1]] = (s32(v[t[2]]) >> t[3]) & 0xffffffff
+            elif op == "or3":
+                v[t[1]] = v[t[2]] | v[t[3]] | v[t[4]]
+            elif op == "flag0":
+                self.count["valu"] += 1
+                if v[t[2]] == 0:
+                    v[t[1]] = 1
             elif op == "awrite":
                 a[t[1]] = v[t[2]]
             elif op == "aread":
@@ -318,6 +332,24 @@ class Builder:
             else:
                 a.e("mov", d.r[i], a.ACC)
         return d.like(1, 0)
+
+    def flag_if_zero(self, flag, parts, scratch):
+        """flag (a VGPR) <- 1 where every one of the values `parts` (Fp objects) is 0 mod p: each is partially reduced (|r| < 0.51 p, so
+        0 mod p means all limbs zero) into `scratch` (one Fp block per part) and the limbs are OR-ed together."""
+        regs = []
+        for x, sc in zip(parts, scratch):
+            regs += self.reduce(sc, x).r
+        t = self.tmp2
+        self.a.e("or3", t, regs[0], regs[1], regs[2])
+        rest = regs[3:]
+        while rest:
+            if len(rest) >= 2:
+                self.a.e("or3", t, t, rest[0], rest[1])
+                rest = rest[2:]
+            else:
+                self.a.e("or3", t, t, rest[0], rest[0])
+                rest = rest[1:]
+        self.a.e("flag0", flag, t)
 
     # ---- the multiplier: Montgomery dot product of operand pairs -> dst (may be M or any operand block, see gen_lineprod_asm.py)
     def dot_body(self, pairs, dst):

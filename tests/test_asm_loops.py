@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 TOOLS = os.path.join(ROOT, "nim-blscurve_amd", "tools")
 
 
@@ -36,6 +37,28 @@ def test_lines_text_is_one_statement():
     assert '"v249"' in t and '"v250"' not in t and '"a255"' in t
     # every store of a line coefficient goes through the running row pointer with the lane's 32-bit byte offset
     assert t.count("global_store_dwordx4") == 2 * 3 * 2 * 3 and t.count("global_store_dwordx2") == 2 * 3 * 2
+
+
+def test_clear_cofactor_kernel_body_matches_bigint_model():
+    """k_hash_clear: single doubling / addition / psi steps with their bounds, the flag on crafted exceptional inputs, and the WHOLE kernel
+    body (loads, P = q0 + q1, both chains, psi maps, the seven outer additions, the store - memory operations emulated) against the
+    reference formula as a group element."""
+    out = run("gen_clear_asm.py", "--selftest")
+    assert "selftest ok" in out
+    m = re.search(r"whole kernel body: (\d+) VALU instructions, (\d+) multiply-adds", out)
+    valu, mads = int(m.group(1)), int(m.group(2))
+    import bench
+    assert abs(mads - bench.MAD_PER_TUPLE["k_hash_clear"]) <= 0.02 * bench.MAD_PER_TUPLE["k_hash_clear"]      # the census bench.py's roofline uses
+    assert valu <= 1_370_000, "the kernel body grew: %d instructions" % valu
+    assert mads / valu > 0.785
+
+
+def test_clear_text_is_one_statement():
+    t = run("gen_clear_asm.py")
+    assert "#define BLS_CLEAR_ASM_BODY" in t and "#define BLS_CLEAR_ASM_CLOBBERS" in t
+    assert "scratch_" not in t
+    assert t.count("s_setpc_b64") == 8                             # four leaf multipliers, PREP, ADD, PSI, CHAIN
+    assert '"v249"' in t and '"v250"' not in t and '"a255"' in t
 
 
 def test_asmlib_reduce_and_carry_against_bigints():
