@@ -1478,6 +1478,20 @@ __global__ void __launch_bounds__(WAVE) k_pip_convert(const uint8_t* __restrict_
     st_aff_int(o, q);
     o[FP_N] = aff_is_inf(q) ? 1u : 0u;                  // first pad word of x: "this point is the point at infinity" (tested once here, not per bucket addition)
 }
+// Round 5: the G1 form of the bucket accumulation is ONE hand-allocated assembly statement (tools/gen_msm_asm.py -> build/msm_asm.inc;
+// curve.hpp's xyzz_add_aff without its exceptional branches, checked by tests/test_asm_loops.py): the nine multiplier bodies of a mixed
+// addition expanded in place on fixed registers (no calls, no operand copies), the NEXT point's record gathered while the current addition
+// runs, 230 VGPRs = two waves per SIMD as before.  A lane whose bucket met an exceptional case (addend == +- accumulator, a point at
+// infinity: ZZ3 = 0 or the record's flag) comes back flagged and recomputes its bucket with the complete compiled formulas below.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_MSM_NOASM)
+#include "../build/msm_asm.inc"
+__device__ __forceinline__ uint32_t msm_bucket_asm(const uint32_t* pts, const uint32_t* srt, uint32_t cnt, uint4* buckets, uint32_t ostride16, uint32_t off16) {
+    uint32_t flag;
+    const uint64_t a = (uint64_t)(uintptr_t)srt;
+    asm volatile(BLS_MSM_ASM_BODY : "=v"(flag) : "s"(pts), "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"(cnt), "s"(buckets), "s"(ostride16), "v"(off16) : BLS_MSM_ASM_CLOBBERS);
+    return flag;
+}
+#endif
 // lane per (window, bucket); `order` lists the buckets so that a wave's lanes have similar counts
 template <class F>
 __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_bucket(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
@@ -1489,6 +1503,11 @@ __global__ void __launch_bounds__(WAVE, sizeof(F) == sizeof(fp) ? 2 : 1) k_pip_b
     uint32_t g = g0 + (order ? order[g0 + t] : t);
     uint32_t w = g >> cbk, cnt = hist[g], off = offs[g];
     const uint32_t* srt = sorted + (size_t)w * n + off;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_MSM_NOASM)
+    if constexpr (sizeof(F) == sizeof(fp)) {
+        if (!msm_bucket_asm(pts, srt, cnt, buckets, total * 16u, g * 16u)) return;        // stored by the loop; flagged lanes fall through to the complete formulas
+    }
+#endif
     xyzz<F> acc = xyzz_inf<F>();                        // extended Jacobian: 8M + 2S per mixed addition (curve.hpp)
     // the first point of a bucket initialises the accumulator (no addition: 3 % of all additions at 32 points per bucket); the
     // "operand is the point at infinity" test was made once by k_pip_convert

@@ -333,6 +333,21 @@ class Builder:
                 a.e("mov", d.r[i], a.ACC)
         return d.like(1, 0)
 
+    def zero_test(self, dst, parts, scratch):
+        """dst (a VGPR) <- the OR of all limbs of the partially reduced values `parts`: zero exactly where every one of them is 0 mod p"""
+        regs = []
+        for x, sc in zip(parts, scratch):
+            regs += self.reduce(sc, x).r
+        self.a.e("or3", dst, regs[0], regs[1], regs[2])
+        rest = regs[3:]
+        while rest:
+            if len(rest) >= 2:
+                self.a.e("or3", dst, dst, rest[0], rest[1])
+                rest = rest[2:]
+            else:
+                self.a.e("or3", dst, dst, rest[0], rest[0])
+                rest = rest[1:]
+
     def flag_if_zero(self, flag, parts, scratch):
         """flag (a VGPR) <- 1 where every one of the values `parts` (Fp objects) is 0 mod p: each is partially reduced (|r| < 0.51 p, so
         0 mod p means all limbs zero) into `scratch` (one Fp block per part) and the limbs are OR-ed together."""
@@ -373,6 +388,41 @@ class Builder:
                 a.e("and_s", dst.r[kk - NL], a.S_MASK, a.ACC)
             a.e("ashr64", 28)
         a.e("mov", dst.r[NL - 1], a.ACC)
+
+    def sqr_body(self, x, x2, dst):
+        """Montgomery square (fp.hpp fp_sqr_core): the 91 off-diagonal products once against the doubled operand x2 = 2 x (the caller
+        provides the 14 registers), so the operand half costs 105 multiply-adds instead of 196.  dst may be x, x2 or M."""
+        a, M = self.a, self.M
+        for i in range(NL):
+            a.e("lshl", x2.r[i], x.r[i], 1)
+        first = True
+        for kk in range(2 * NL - 1):
+            lo = 0 if kk < NL else kk - NL + 1
+            i = lo
+            while 2 * i < kk:
+                a.mad(x2.r[i], ("v", x.r[kk - i]), first)
+                first = False
+                i += 1
+            if kk % 2 == 0:
+                a.mad(x.r[kk // 2], ("v", x.r[kk // 2]), first)
+                first = False
+            if kk < NL:
+                for i in range(kk):
+                    a.mad(M[i], ("s", a.S_P + kk - i))
+                a.e("mul_lo", M[kk], a.ACC, a.S_N0)
+                a.e("and_s", M[kk], a.S_MASK, M[kk])
+                a.mad(M[kk], ("s", a.S_P))
+            else:
+                for i in range(kk - NL + 1, NL):
+                    a.mad(M[i], ("s", a.S_P + kk - i))
+                a.e("and_s", dst.r[kk - NL], a.S_MASK, a.ACC)
+            a.e("ashr64", 28)
+        a.e("mov", dst.r[NL - 1], a.ACC)
+
+    def sqr(self, x, x2, dst):
+        assert x.vb * x.vb <= 2048 and _u(x.lb) <= 2, "sqr operand bounds"
+        self.sqr_body(x, x2, dst)
+        return dst.like(2, 0)
 
     def dot(self, pairs, dst):
         """checked form: fp_dotn's preconditions"""

@@ -97,3 +97,20 @@ def test_asmlib_reduce_and_carry_against_bigints():
         mach.run(a.ins)
         assert al.get(mach, x) == val
         al.check_limbs(mach, x, 1)
+
+
+def test_msm_bucket_loop_matches_bigint_model():
+    """k_pip_bucket<fp>: the mixed addition in extended Jacobian coordinates on random points with both signs, the final conversion, and the
+    complete formula's exceptional branches driven through the loop's own control flow (q + q: the doubling path; q - q: infinity; infinity + r)."""
+    out = run("gen_msm_asm.py", "--selftest")
+    assert "selftest ok" in out
+    m = re.search(r"(\d+) VALU instructions per addition \((\d+) multiply-adds", out)
+    valu, mads = int(m.group(1)), int(m.group(2))
+    assert mads == 3600 and valu <= 4500          # 6 products, 2 squares, one two-term dot product (3 542) + the two partial reductions (58)
+
+
+def test_msm_text_is_one_statement():
+    t = run("gen_msm_asm.py")
+    assert "#define BLS_MSM_ASM_BODY" in t and "#define BLS_MSM_ASM_CLOBBERS" in t
+    assert "scratch_" not in t and "s_swappc" not in t            # no spills, no calls: the multiplier bodies are expanded in place
+    assert '"v229"' in t and '"v230"' not in t and '"a0"' not in t  # 230 VGPRs, no AGPRs: two waves per SIMD
