@@ -1669,7 +1669,9 @@ struct team_wave_fp {               // every lane of the wave holds the same poi
     }
     __device__ __forceinline__ fp mul1(const fp& a, const fp& b) const { return fp_mul(a, b); }
 };
-__device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) { return jac_dbl_team(p, team_wave_fp{}); }
+// (round 5: the quad team's DPP exchanges instead of team_wave_fp's wave shuffles - every lane holds the same point, so every quad is a team:
+// the 112 - 240 dependent doublings of a window sum are what the MSM waits for now)
+__device__ __forceinline__ g1_jac g1_dbl_coop(const g1_jac& p) { return jac_dbl_team(p, team_quad_fp<4>{threadIdx.x & 3u}); }
 __device__ __forceinline__ g1_jac dbl_coop(const g1_jac& p) { return g1_dbl_coop(p); }
 __device__ __forceinline__ g2_jac dbl_coop(const g2_jac& p) { return g2_dbl_coop(p, threadIdx.x & ~7u, threadIdx.x & 7u); }
 __device__ __forceinline__ g1_jac bcast0(const g1_jac& a) { return g1_jac{fp_bcast(a.x, 0), fp_bcast(a.y, 0), fp_bcast(a.z, 0)}; }
