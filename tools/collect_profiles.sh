@@ -1,5 +1,5 @@
 # The evidence under profiles/ (round tag $TAG, default r04).  On the GPU box: bash tools/collect_profiles.sh
-R=$GRAFT_REPO_ROOT; TAG=${TAG:-r04}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; TAG=${TAG:-r05}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu --no-aux --no-one-caller"
 # kernel-trace statistics: the default bench command (3 chained batches in flight), the same kernels alone (one throughput-mode
 # caller), one latency-mode caller, and the aux configs (MSM 2^20, fastAggregateVerify 32768, 4096-tuple batch)

@@ -1,5 +1,7 @@
 # On the GPU box: pipelined step time against the number of batches in flight and the chaining event, two passes
+# (MI355_BLS_CHAIN_EV exists only in a build made with BLS_EXTRA_FLAGS=-DBLS_EXPERIMENTS: LIB=<name> selects nim-blscurve_amd/variants/<name>.so)
 cd $GRAFT_REPO_ROOT
+[ -n "$LIB" ] && export MI355_BLS_LIB=$GRAFT_REPO_ROOT/nim-blscurve_amd/variants/$LIB.so
 for pass in 1 2; do
 for cfg in "3 -" "2 -" "4 -" "3 hm" "3 clear" "3 sig" "3 lines"; do
   set -- $cfg
