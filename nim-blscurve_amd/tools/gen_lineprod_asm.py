@@ -300,9 +300,9 @@ def kernel_text():
 
 
 def clobbers():
-    # m0 (LDS-DMA base) and scc (s_cmp / s_sub / s_cselect) are written too; exec is changed (saveexec / s_mov exec) and left at -1: the statement
+    # m0 (LDS-DMA base; LLVM refuses it on a clobber list: a reserved register) and scc (s_cmp / s_sub / s_cselect) are written too; exec is changed (saveexec / s_mov exec) and left at -1: the statement
     # is the LAST thing of its kernel branch (k_lineprod returns right behind it) - nothing may be placed after it that assumes m0 or exec
-    c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(S_P, S_RET + 2)] + ["vcc", "scc", "m0", "memory"]
+    c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(S_P, S_RET + 2)] + ["vcc", "scc", "memory"]
     return ", ".join('"%s"' % x for x in c)
 
 

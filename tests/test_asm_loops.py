@@ -114,3 +114,20 @@ def test_msm_text_is_one_statement():
     assert "#define BLS_MSM_ASM_BODY" in t and "#define BLS_MSM_ASM_CLOBBERS" in t
     assert "scratch_" not in t and "s_swappc" not in t            # no spills, no calls: the multiplier bodies are expanded in place
     assert '"v229"' in t and '"v230"' not in t and '"a0"' not in t  # 230 VGPRs, no AGPRs: two waves per SIMD
+
+
+def test_pkmul_blocks_match_bigint_model():
+    """k_pkmul: the table of 1 .. 8 times the key with each entry's Z^2, Z^3, then 17 windows of four doublings and one signed table addition
+    (biased digits), block by block against big-integer Jacobian arithmetic; acc == entry is detected (Z3 == 0)."""
+    out = run("gen_pkmul_asm.py", "--selftest")
+    assert "selftest ok" in out
+    m = re.search(r"doubling (\d+) instructions \((\d+) multiply-adds\), addition (\d+) \((\d+)\)", out)
+    nd, md, na, ma = (int(x) for x in m.groups())
+    assert md == 2334 and ma == 5077 and nd <= 3050 and na <= 6700
+
+
+def test_pkmul_text_is_one_statement():
+    t = run("gen_pkmul_asm.py")
+    assert "#define BLS_PKMUL_ASM_BODY" in t and "#define BLS_PKMUL_ASM_CLOBBERS" in t
+    assert "scratch_" not in t and '"a0"' not in t and '"v241"' in t and '"v242"' not in t      # VGPRs only, two waves per SIMD
+    assert t.count("v_mad_i64_i32") < 7000          # the hot code (two shared bodies, the doubling, the addition's glue) stays near 40 KB
