@@ -41,7 +41,7 @@ typedef struct mi355_bls_ctx mi355_bls_ctx;
 
 /* BatchedBLSVerifierCache.init / init(tp) (bls_batch_verifier.nim:108-119): persistent device
  * workspace on HIP device `device`.  One context per concurrent caller, reusable across calls
- * (bls_batch_verifier.nim:389-391).  max_sets sizes the workspace (about 29 KB of HBM per set), it does NOT bound
+ * (bls_batch_verifier.nim:389-391).  max_sets sizes the workspace (about 32 KB of HBM per set), it does NOT bound
  * input.len: like the reference's cache (per-thread contexts only, :108-119,:141) every batchVerify entry point accepts
  * any n - a batch (or shard) larger than max_sets is processed in ceil(n / max_sets) balanced slices on the same stream,
  * whose committed states are merged on the device (blst_pairing_merge semantics).  Size it for the batches you expect:

@@ -609,20 +609,21 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restric
 // other's issue gaps (non-multiply VALU instructions issue about twice as fast with a second wave on the SIMD)
 // Round 5: the scalar multiplication is ONE hand-allocated assembly statement (tools/gen_pkmul_asm.py -> build/pkmul_asm.inc; curve.hpp's
 // jac_mul_u64_w4_body with biased signed digits, jac_dbl_lazy's G1 form and jac_precompute + jac_add_pre, checked by tests/test_asm_loops.py):
-// multiplier bodies in place on fixed registers, the table of 1 .. 8 times the key (with each entry's Z^2, Z^3) in per-lane columns of `scratch`
-// (rows 48 .. 207 of the context's line store, unused at this stage; the compiled kernel indexed a table in scratch memory: 95 x over-fetch, 16 %
-// of its cycles waiting), a window's entry gathered before the window's four doublings.  A lane whose addition met Z3 == 0 (possible only for a
+// the doubling's multiplier bodies in place on fixed registers, the addition's products through two shared bodies (the loop stays inside the
+// instruction cache), the table of 1 .. 8 times the key (with each entry's Z^2, Z^3) in `table`, a buffer of the context with 2 560 contiguous bytes
+// per lane (the compiled kernel indexed a table in scratch memory: 16 % of its cycles waiting), a window's entry gathered before the window's four
+// doublings.  A lane whose addition met Z3 == 0 (possible only for a
 // key outside G1) is flagged and recomputed below with the complete formulas.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_PKMUL_NOASM)
 #include "../build/pkmul_asm.inc"
-__device__ __forceinline__ uint32_t pkmul_asm(uint64_t r, uint4* scratch, uint32_t sstride16, uint32_t off16, uint4* P, uint32_t pstride16, uint32_t lds) {
+__device__ __forceinline__ uint32_t pkmul_asm(uint64_t r, uint8_t* table, uint32_t off16, uint4* P, uint32_t pstride16, uint32_t lds) {
     uint32_t flag;
-    asm volatile(BLS_PKMUL_ASM_BODY : "=v"(flag) : "v"((uint32_t)r), "v"((uint32_t)(r >> 32)), "s"(scratch), "s"(sstride16), "v"(off16), "s"(P), "s"(pstride16), "s"(lds) : BLS_PKMUL_ASM_CLOBBERS);
+    asm volatile(BLS_PKMUL_ASM_BODY : "=v"(flag) : "v"((uint32_t)r), "v"((uint32_t)(r >> 32)), "s"(table), "s"(0u), "v"(off16), "s"(P), "s"(pstride16), "s"(lds) : BLS_PKMUL_ASM_CLOBBERS);
     return flag;
 }
 #endif
 __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
-                                                   size_t stride, uint32_t* __restrict__ flags, uint4* __restrict__ scratch) {
+                                                   size_t stride, uint32_t* __restrict__ flags, uint8_t* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
@@ -630,13 +631,13 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
     const bool inf = aff_is_inf(pk);
     if (inf) atomicOr(flags, 1u);        // BLST_PK_IS_INFINITY -> update() false
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_PKMUL_NOASM)
-    if (scratch && stride * 16 * 20 < ((size_t)1 << 32)) {          // wave-uniform: the table's row arithmetic is 32-bit
+    if (table) {                                                     // the context's table buffer (MI355_BLS_PKTAB_BYTES per set)
         __shared__ bls_u32x4 key_slot[BLS_LDS_SLOT];
         if (inf) {
             soa_st_g1(P, stride, i, jac_inf<fp>());
         } else {
             fp2_lds_put((bls_lds_u32x4*)key_slot, fp2{pk.x, pk.y});
-            if (pkmul_asm(r[i], scratch + 48 * stride, (uint32_t)(stride * 16), i * 16u, P, (uint32_t)(stride * 16), (uint32_t)(uintptr_t)(bls_lds_u32x4*)key_slot))
+            if (pkmul_asm(r[i], table, i * 16u, P, (uint32_t)(stride * 16), (uint32_t)(uintptr_t)(bls_lds_u32x4*)key_slot))
                 soa_st_g1(P, stride, i, jac_mul_u64_w4_body(pk, r[i]));
         }
         return;

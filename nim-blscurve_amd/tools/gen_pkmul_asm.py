@@ -9,9 +9,9 @@ Z^3 (curve.hpp jac_precompute), then per window four doublings (jac_dbl_lazy's G
 +-entry (jac_add_pre: 3 squares, 9 products, one a b - c d).
 Why assembly: the compiled kernel (0.69 multiply-add share, 16 % of its wave cycles waiting, 1.5 GB of HBM traffic for 16 MB of input) keeps its
 table in scratch memory, indexed by a per-lane digit right where it is needed.  Here the multiplier bodies are expanded in place on fixed
-registers (G1 needs no subroutines; VGPRs only: two waves per SIMD as before), the table lives in per-lane columns of a global scratch area
-(rows 48.. of the context's line store, unused at this stage) and a window's entry is gathered BEFORE the window's four doublings, i.e. ~12 000
-instructions ahead of its use.
+registers (VGPRs only: two waves per SIMD as before), the table lives in a global buffer of the context, 2 560 contiguous bytes per lane (8 entries x
+5 coordinates x 64 bytes: a gather reads exactly its 320 bytes, every row address is an immediate offset), and a window's entry is gathered BEFORE
+the window's four doublings, i.e. ~12 000 instructions ahead of its use.
 Exceptional cases: the accumulator is "not started" until the first non-zero digit (that entry is copied, not added); an addition that meets
 acc == +-entry cannot happen for a point of G1 (16 x prefix = +-d has no solution with 0 < |d| <= 8) - Z3 == 0 after an addition raises the
 lane's flag and the kernel recomputes the lane with the compiled complete formulas (keys outside G1 that a caller did not subgroup-check).
@@ -274,54 +274,50 @@ def selftest(seed=4):
 
 
 # ---- text ---------------------------------------------------------------------------------------------------------------------------
-def rows_uniform(store, blocks, entry_sreg_ready=True):
-    """the rows of ONE table entry with a wave-uniform index (row pointer S_GP already set): 4 rows per 14-limb block, address = row pointer + V_OFF"""
+ENTRY_BYTES, LANE_BYTES = 320, 8 * 320
+
+
+def rows_uniform(store, blocks, e):
+    """the rows of table entry e (wave-uniform index): address = this lane's table (V_COL, 64-bit) + an immediate"""
     t = []
-    for base in blocks:
+    for c, base in enumerate(blocks):
         for q in range(4):
             n = 4 if q < 3 else 2
             r = base + 4 * q
+            off = e * ENTRY_BYTES + 64 * c + 16 * q
             if store:
-                t.append("global_store_dwordx%d v%d, v[%d:%d], s[%d:%d]" % (n, V_OFF, r, r + n - 1, S_GP, S_GP + 1))
+                t.append("global_store_dwordx%d v[%d:%d], v[%d:%d], off offset:%d" % (n, V_COL, V_COL + 1, r, r + n - 1, off))
             else:
-                t.append("global_load_dwordx%d v[%d:%d], v%d, s[%d:%d]" % (n, r, r + n - 1, V_OFF, S_GP, S_GP + 1))
-            t += ["s_add_u32 s%d, s%d, s%d" % (S_GP, S_GP, S_STR), "s_addc_u32 s%d, s%d, 0" % (S_GP + 1, S_GP + 1)]
-    return t
-
-
-def entry_ptr(e):
-    """S_GP <- table base + e * (20 rows)"""
-    t = ["s_mov_b64 s[%d:%d], s[%d:%d]" % (S_GP, S_GP + 1, S_TAB, S_TAB + 1)]
-    for _ in range(e):
-        t += ["s_add_u32 s%d, s%d, s%d" % (S_GP, S_GP, S_ESTR), "s_addc_u32 s%d, s%d, 0" % (S_GP + 1, S_GP + 1)]
+                t.append("global_load_dwordx%d v[%d:%d], v[%d:%d], off offset:%d" % (n, r, r + n - 1, V_COL, V_COL + 1, off))
     return t
 
 
 def store_entry(e):
-    return ["s_swappc_b64 s[%d:%d], s[%d:%d]" % (S_T, S_T + 1, S_M5, S_M5 + 1)] + entry_ptr(e) + rows_uniform(True, [AX.r[0], AY.r[0], AZ.r[0], T[0].r[0], T[1].r[0]])
+    return ["s_swappc_b64 s[%d:%d], s[%d:%d]" % (S_T, S_T + 1, S_M5, S_M5 + 1)] + rows_uniform(True, [AX.r[0], AY.r[0], AZ.r[0], T[0].r[0], T[1].r[0]], e)
 
 
 def load_acc_entry(e):
-    return ["s_waitcnt vmcnt(0)"] + entry_ptr(e) + rows_uniform(False, [AX.r[0], AY.r[0], AZ.r[0]]) + ["s_waitcnt vmcnt(0)"]
+    return ["s_waitcnt vmcnt(0)"] + rows_uniform(False, [AX.r[0], AY.r[0], AZ.r[0]], e) + ["s_waitcnt vmcnt(0)"]
 
 
 def kernel_text():
-    """operands: %0 flag out (v); %1, %2 the scalar r (v, v: low, high word); %3 table scratch (s pair: this launch's rows of per-lane columns); %4 row stride
-    of the scratch in bytes (s); %5 16 * the lane's column (v); %6 output P (s pair: SoA, three planes); %7 its row stride in bytes (s); %8 LDS address of the
-    slot holding the key (x, y) in fp2_lds_put's layout (s)"""
+    """operands: %0 flag out (v); %1, %2 the scalar r (v, v: low, high word); %3 table buffer (s pair: 2 560 bytes per lane); %4 unused (s); %5 16 * the lane's
+    index (v); %6 output P (s pair: SoA, three planes); %7 its row stride in bytes (s); %8 LDS address of the slot holding the key (x, y) in fp2_lds_put's
+    layout (s)"""
     dbl, _ = gen_dbl()
     add, _ = gen_add()
     Tx = []
     Tx += ["s_mov_b32 s%d, 0x%x" % (S_P + i, PL[i]) for i in range(NL)]
     Tx += ["s_mov_b32 s%d, 0x%x" % (S_N0, N0), "s_mov_b32 s%d, 0x%x" % (S_MASK, MASK), "s_mov_b32 s%d, 0x%x" % (S_RECIP, RECIP)]
-    Tx += ["s_mov_b64 s[%d:%d], %%3" % (S_TAB, S_TAB + 1), "s_mov_b32 s%d, %%4" % S_STR, "s_mov_b32 s%d, 0" % (S_STR + 1), "s_mul_i32 s%d, %%4, 20" % S_ESTR,
+    Tx += ["s_mov_b64 s[%d:%d], %%3" % (S_TAB, S_TAB + 1), "s_mov_b32 s%d, %d" % (S_ESTR, ENTRY_BYTES),
            "s_mov_b64 s[%d:%d], %%6" % (S_OUT, S_OUT + 1), "s_mov_b32 s%d, %%7" % S_OSTR, "s_mov_b64 s[%d:%d], exec" % (S_EXEC, S_EXEC + 1)]
     Tx += ["v_mov_b32_e64 v%d, %%5" % V_OFF, "v_mov_b32_e64 v%d, 0" % V_FLAG, "v_mov_b32_e64 v%d, 0" % V_ST]
     # k' = r + 0x8888888888888888, the carry is digit 16
     Tx += ["v_mov_b32_e32 v%d, 0x88888888" % V_T, "v_add_co_u32_e32 v%d, vcc, v%d, %%1" % (V_KLO, V_T), "v_addc_co_u32_e32 v%d, vcc, v%d, %%2, vcc" % (V_KHI, V_T),
            "v_cndmask_b32_e64 v%d, 0, 1, vcc" % V_CARRY]
     # this lane's column as a 64-bit address: table base + 16 * column
-    Tx += ["v_mov_b32_e64 v%d, v%d" % (V_COL, V_OFF), "v_mov_b32_e64 v%d, 0" % (V_COL + 1),
+    Tx += ["v_lshrrev_b32_e64 v%d, 4, v%d" % (V_T, V_OFF), "s_mov_b32 s%d, %d" % (S_SH, LANE_BYTES),
+           "v_mad_u64_u32 v[%d:%d], vcc, v%d, s%d, 0" % (V_COL, V_COL + 1, V_T, S_SH),
            "v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, s[%d:%d]" % (V_COL, V_COL + 1, V_COL, V_COL + 1, S_TAB, S_TAB + 1)]
     # the key from LDS: 28 words (x limbs, y limbs) -> T0, T1 (contiguous), then the accumulator = (x, y, 1) = entry 1; the E registers keep it for the odd entries
     Tx += ["v_mbcnt_lo_u32_b32 v%d, -1, 0" % TMP, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (TMP, TMP), "v_lshlrev_b32_e64 v%d, 4, v%d" % (TMP, TMP),
@@ -376,11 +372,10 @@ def kernel_text():
            "s_cbranch_execz .Lpk_nog%=",
            "v_add_u32_e64 v%d, -1, v%d" % (V_T, V_D),
            "v_mad_u64_u32 v[%d:%d], vcc, v%d, s%d, v[%d:%d]" % (V_TA, V_TA + 1, V_T, S_ESTR, V_COL, V_COL + 1)]
-    for base in E0:
+    for c, base in enumerate(E0):
         for q in range(4):
             n = 4 if q < 3 else 2
-            Tx.append("global_load_dwordx%d v[%d:%d], v[%d:%d], off" % (n, base + 4 * q, base + 4 * q + n - 1, V_TA, V_TA + 1))
-            Tx.append("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, s[%d:%d]" % (V_TA, V_TA + 1, V_TA, V_TA + 1, S_STR, S_STR + 1))
+            Tx.append("global_load_dwordx%d v[%d:%d], v[%d:%d], off offset:%d" % (n, base + 4 * q, base + 4 * q + n - 1, V_TA, V_TA + 1, 64 * c + 16 * q))
     Tx += [".Lpk_nog%=:", "s_mov_b64 exec, s[%d:%d]" % (S_SV, S_SV + 1)]
     # four doublings (none in front of digit 16)
     Tx += ["s_cmp_eq_u32 s%d, 16" % S_J, "s_cbranch_scc1 .Lpk_nodbl%=", "s_mov_b32 s%d, 4" % S_K, ".Lpk_d4%=:"] + cdbl + \
