@@ -287,3 +287,42 @@ def test_randomised_batches_against_the_c_oracle(m):
                 assert cache.fetch(4, 576) == st["gt"], (it, n, defect, nt, coop)
     for c in caches.values():
         c.close()
+
+
+def test_keys_outside_g1_take_the_complete_formulas(m):
+    """batchVerify is handed validated keys, but the kernel must not depend on it: k_pkmul's assembly loop uses incomplete additions with ONE zero test
+    (Z3 == 0 -> the lane is recomputed with the complete formulas).  Keys of order 3 ((0, +-2): their window table holds the point at infinity) and keys of
+    full order h * r (on the curve, outside G1) among ordinary ones, in both modes and beyond one wave: [r_i]PK_i equal to the oracle's scalar
+    multiplication for EVERY tuple, verdict and GT equal to the C restatement's."""
+    import c_oracle as co
+    n = 150
+    rec = bytearray(co.make_batch(n, seed=777))
+    odd = {}
+    odd[0] = (0, 2)
+    odd[1] = (0, o.P - 2)
+    odd[64] = (0, 2)
+    x = 1
+    for slot in (2, 63, 65, 129, 149):
+        while True:
+            x += 1
+            y = o.fp_sqrt((x * x * x + 4) % o.P)
+            if y is not None and not o.g1_in_subgroup((x, y)):
+                break
+        odd[slot] = (x, y)
+    for slot, pt in odd.items():
+        assert o.g1_on_curve(pt)
+        rec[320 * slot:320 * slot + 96] = o.g1_to_blst_affine(pt)
+    rec = bytes(rec)
+    rnd = o.sha256(b"outside G1")
+    for coop in (True, False):
+        cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=4)
+        cache.set_cooperative(coop)
+        want, st = co.batch_verify(rec, rnd, 4, stages=True)
+        assert m.batchVerify(cache, rec, rnd) == want
+        r = struct.unpack("<%dQ" % n, cache.fetch(0, 8 * n))
+        P = cache.fetch(2, 144 * n)
+        for i in range(n):
+            pk = o.g1_from_blst_affine(rec[320 * i:320 * i + 96])
+            assert g1_jac_to_affine(P[144 * i:144 * i + 144]) == o.g1_mul(pk, r[i]), (i, coop)
+        assert cache.fetch(4, 576) == st["gt"]
+        cache.close()
