@@ -660,7 +660,7 @@ def one_caller_rows(m, cache, cache_tp, stream, d_sets, n, n_total, lo, hi, rnd,
     alone.update({KERNEL_OF_STAGE[k]: v for k, v in acc.items() if k in KERNEL_OF_STAGE})
     alone["k_sig_bucket"] = acc.get("sig_mul_sum", 0.0)
     out["kernel_alone_ms"] = {k: v for k, v in alone.items() if v > 0}
-    out["tail_ms_alone"] = {"k_lineprod2": acc.get("k_lineprod2", 0.0), "final": acc.get("final", 0.0)}
+    out["tail_ms_alone"] = {"fold_of_line_products": acc.get("k_lineprod2", 0.0), "final": acc.get("final", 0.0)}      # a lone caller folds with k_fold
     if not sharded_path:
         host = d_sets.cpu().numpy().tobytes()                      # pageable host memory, as a Nim seq would be
         assert m.batchVerifyParallel(cache, host, rnd)

@@ -163,6 +163,19 @@ def test_cooperative_and_plain_kernels_agree(m):
         assert g2_jac_to_affine(Ha[288 * i:288 * i + 288]) == g2_jac_to_affine(Hb[288 * i:288 * i + 288])
     ok, st = co.batch_verify(rec, rnd, 64, stages=True)
     assert ok and st["gt"] == a.fetch(4, 576)
+    # the fold of the line products: a call enqueued while nothing else is in flight uses the Fp12 engine (k_fold) in either mode; with another
+    # context's batch pending the one-lane-per-set context takes k_lineprod2.  Same GT bytes.
+    import torch
+    d = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+    other = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=64)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    other.submit_device(d.data_ptr(), n, rnd, s.cuda_stream)
+    assert b.verify_device(d.data_ptr(), n, rnd) is True
+    assert other.wait() is True
+    assert b.fetch(4, 576) == st["gt"] and other.fetch(4, 576) == st["gt"]
+    for c in (a, b, other):
+        c.close()
 
 
 def test_submit_wait(m):

@@ -60,6 +60,16 @@ def test_stage_parity_at_headline_sizes(m, n):
     assert tp.verify_device(d.data_ptr(), n, RND) is True
     assert tp.fetch(4, 576) == st["gt"]
     assert o.g2_to_blst_affine(g2_jac_to_affine(tp.fetch(3, 288))) == st["aggsig"]
+    # ... and with another context's batch in flight, as in the timed region (a lone caller folds on the engine in either mode)
+    import torch
+    other = m.BatchedBLSVerifierCache.init(max_sets=64, numThreads=4)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    other.submit_device(d.data_ptr(), 64, RND, side.cuda_stream)
+    assert tp.verify_device(d.data_ptr(), n, RND) is True
+    assert other.wait() is True
+    assert tp.fetch(4, 576) == st["gt"]
+    other.close()
     tp.close()
     bad = d.clone()
     i, j = n - 1, n // 2
