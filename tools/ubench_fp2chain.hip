@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, uint64_t* stamps, int ite
     if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 int main(int argc, char** argv) {
-    // usage: ubench_fp2chain.bin [iters [waves]]   (bench.py runs "4000 0": ~20 ms on every SIMD of the chip, one line of output)
+    // usage: ubench_fp2chain.bin [iters [only [waves_per_simd]]]   (bench.py runs "4000 0": ~20 ms on every SIMD of the chip, one line of output)
     const int iters_arg = argc > 1 ? atoi(argv[1]) : 20000;
     int nsimd = 1024;
     {
@@ -49,8 +49,9 @@ int main(int argc, char** argv) {
         if (hipGetDeviceProperties(&prop, 0) == hipSuccess) nsimd = 4 * prop.multiProcessorCount;
     }
     const int only = argc > 2 ? atoi(argv[2]) : -1;          // 0: the whole chip only
-    for (int blocks : {nsimd, nsimd / 8}) {
-        if (only == 0 && blocks != nsimd) continue;
+    const int per_simd = argc > 3 ? atoi(argv[3]) : 1;       // waves per SIMD (the kernel needs 72 registers: up to 7 fit)
+    for (int blocks : {nsimd * per_simd, nsimd / 8}) {
+        if (only == 0 && blocks != nsimd * per_simd) continue;
         uint32_t* out; uint64_t* st; int iters = iters_arg;
         (void)hipMalloc(&out, (size_t)blocks * 64 * 4); (void)hipMalloc(&st, blocks * 16);
         k<<<blocks, 64>>>(out, st, 200);
@@ -64,6 +65,11 @@ int main(int argc, char** argv) {
         double instr = (double)iters * BODIES * INSTR_PER_BODY, mads = (double)iters * BODIES * MADS_PER_BODY;
         double rate = mads * 64.0 * blocks / (ms * 1e-3);                 // multiply-adds per second, whole launch
         double peak = (double)nsimd * 64 * 2.4e9 / 4;
+        if (blocks > nsimd) {            // several waves per SIMD: cycles per instruction PER SIMD
+            printf("dot2 chain, %4d waves (%d per SIMD): cycles/instr per wave %.3f = %.3f per SIMD  in-kernel clock %.3f GHz  multiply-adds/s %.2f T  (%.3f of the nominal peak %.1f T)\n", blocks, per_simd,
+                   (double)h[0] / instr, (double)h[0] / instr / per_simd, (double)h[0] / ((double)h[1] * 10.0), rate / 1e12, rate / peak, peak / 1e12);
+            continue;
+        }
         printf("dot2 chain, %4d waves: cycles/instr %.3f  in-kernel clock %.3f GHz  multiply-adds/s %.2f T  (%.3f of the nominal peak %.1f T when all 1024 SIMDs run)\n", blocks,
                (double)h[0] / instr, (double)h[0] / ((double)h[1] * 10.0), rate / 1e12, rate * ((double)nsimd / blocks) / peak, peak / 1e12);
     }
