@@ -392,6 +392,10 @@ int mi355_bls_debug_g2_clear_cofactor(mi355_bls_ctx* ctx, const uint8_t* in_pair
  * device's shard was handed to its stream (the start skew between devices); returns the number of devices recorded. */
 int mi355_bls_debug_fail_next_enqueue(mi355_bls_ctx* ctx);
 size_t mi355_bls_debug_multi_enqueue_us(float* out, size_t cap);
+/* Batches submitted and not yet waited for, over all contexts of the process: what the library looks at when it chooses between the
+ * low-latency and the least-work fold of the line products (a batch enqueued while this is zero has the chip to itself).  The tests
+ * check that submit / wait / destroy keep it balanced. */
+int mi355_bls_debug_batches_in_flight(void);
 
 #ifdef __cplusplus
 }

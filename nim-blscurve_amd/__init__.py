@@ -126,6 +126,7 @@ def lib():
         L.mi355_bls_p2s_add.argtypes = [vp, ctypes.c_char_p, cp, sz]
         L.mi355_bls_p1s_add_device.argtypes = [vp, ctypes.c_char_p, vp, sz, sz, vp]
         L.mi355_bls_debug_fail_next_enqueue.argtypes = [vp]
+        L.mi355_bls_debug_batches_in_flight.argtypes = []
         L.mi355_bls_debug_g2_clear_cofactor.argtypes = [vp, cp, sz, cp]
         L.mi355_bls_debug_multi_enqueue_us.argtypes = [ctypes.POINTER(ctypes.c_float), sz]
         L.mi355_bls_debug_multi_enqueue_us.restype = sz

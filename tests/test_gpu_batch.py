@@ -208,6 +208,21 @@ def test_submit_wait(m):
     assert dict(got) == {i: (d is d_ok) for i, d in enumerate(plan)}
     with pytest.raises(m.BlsGpuError):
         caches[0].wait()                                                              # nothing pending
+    # the process-wide count of batches in flight (it picks the fold of the line products) stays balanced: submit +1, wait -1,
+    # a refused submit 0, a context destroyed with its batch pending -1
+    L = m.lib()
+    assert L.mi355_bls_debug_batches_in_flight() == 0
+    caches[1].submit_device(d_ok.data_ptr(), n, rnd, streams[1].cuda_stream)
+    caches[2].submit_device(d_bad.data_ptr(), n, rnd, streams[2].cuda_stream)
+    assert L.mi355_bls_debug_batches_in_flight() == 2
+    with pytest.raises(m.BlsGpuError):
+        caches[1].submit_device(d_ok.data_ptr(), n, rnd, streams[1].cuda_stream)
+    assert L.mi355_bls_debug_batches_in_flight() == 2
+    assert caches[1].wait() is True
+    assert L.mi355_bls_debug_batches_in_flight() == 1
+    torch.cuda.synchronize()
+    caches[2].close()                                                                 # never waited for
+    assert L.mi355_bls_debug_batches_in_flight() == 0
     assert caches[0].verify_device(d_ok.data_ptr(), n, rnd) is True
 
 
