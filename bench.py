@@ -623,10 +623,85 @@ def main():
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
             if "aux" in out and "latency_curve" in out["aux"]:
                 out["crossover"] = crossover(out["aux"]["latency_curve"], out["cpu_baseline"])
+        flatten_for_driver(out)
         print(json.dumps(out), flush=True)
     if sharded_path:
         dist.barrier()
         dist.destroy_process_group()
+
+
+HOT_KERNELS = ("k_hash_map", "k_hash_clear", "k_pkmul", "k_lines", "k_lineprod", "k_sig_bucket")
+LATENCY_KERNELS = ("k_hash_one", "k_team_vm", "k_tail", "k_fold")
+
+
+def kernel_meta():
+    """register / spill table build.sh leaves beside the library (tools/kernel_metadata.py --json), or None"""
+    p = os.path.join(ROOT, "nim-blscurve_amd", "libblscurve_mi355x.so.kmeta.json")
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return None
+
+
+def flatten_for_driver(out):
+    """The driver's record keeps `config` and the FLAT scalars of `roofline` / `cpu_baseline` and drops every other key and every nested object
+    (BENCH_r05.json: extra_keys).  The figures the review reads - the bound that matters, its ceiling, BASELINE's second metric, the latency
+    rows - are therefore repeated here as flat scalars in the three objects that survive.  Nothing new is measured."""
+    rf, cfg = out["roofline"], out["config"]
+    im = rf.get("int_mad") or {}
+    ce = im.get("ceiling") or {}
+    rf["int_mad_frac"] = im.get("frac")
+    rf["int_mad_tmads"] = im.get("achieved")
+    rf["int_mad_peak_tmads"] = im.get("peak")
+    rf["int_mad_over_ceiling"] = ce.get("achieved_over_ceiling")
+    rf["ceiling_tmads"] = ce.get("achievable")
+    rf["ceiling_clock_ghz"] = ce.get("clock_ghz")
+    rf["ceiling_measured_on_this_box"] = ce.get("measured_on_this_box")
+    km = kernel_meta()
+    if km:
+        # spills inside the assembly statements are zero by construction; what the metadata counts for the four assembly kernels is their
+        # compiled prologue / flagged-lane fallback, so the figure is an upper bound of what the hot loops touch
+        rf["vgpr_spill_max_hot"] = max((km[k]["spill"] or 0) for k in HOT_KERNELS if k in km)
+        rf["vgpr_spill_max_latency"] = max([(v["spill"] or 0) for k, v in km.items() if k.split("<")[0] in LATENCY_KERNELS] or [0])
+    for k, row in (rf.get("kernels") or {}).items():
+        if row.get("ms_alone"):
+            rf["ms_alone_" + k] = row["ms_alone"]
+    cfg["ms_one_caller"] = out.get("ms_one_caller")
+    cfg["ms_one_caller_sliced_2pow20"] = out.get("ms_one_caller_sliced_2^20")
+    cfg["build_stamp"] = (out.get("build") or {}).get("stamp")
+    cfg["build_aligned"] = (out.get("build") or {}).get("aligned")
+    aux = out.get("aux") or {}
+    msm = aux.get("g1_msm_2^20") or {}
+    cfg["msm_points_per_s"] = msm.get("points_per_s")
+    cfg["msm_ms_per_call"] = msm.get("ms_per_call")
+    cfg["msm_ms_two_in_flight"] = msm.get("ms_per_msm_two_in_flight")
+    cfg["fav_32768_ms"] = (aux.get("fastAggregateVerify_32768") or {}).get("ms_per_call")
+    cfg["verify_one_signature_ms"] = (aux.get("verify_one_signature") or {}).get("ms_per_call")
+    cfg["batch_64_ms"] = (aux.get("batchVerify_64") or {}).get("ms_per_blocking_call")
+    cfg["batch_4096_ms"] = (aux.get("batchVerify_4096") or {}).get("ms_per_blocking_call")
+    cfg["batch_4096_vps_16_in_flight"] = (aux.get("batchVerify_4096") or {}).get("verifications_per_s_16_in_flight")
+    cfg["from_bytes_65536_ms"] = (aux.get("fromBytes_65536") or {}).get("ms_per_call")
+    lc = aux.get("latency_curve") or []
+    if lc:
+        cfg["latency_floor_ms"] = min(r["ms_per_blocking_call"] for r in lc)
+    cb = out.get("cpu_baseline")
+    if cb:
+        co = out.get("crossover") or {}
+        cb["speedup_vs_cpu_port"] = out.get("speedup_vs_cpu_port")
+        cb["gpu_faster_than_blst_model_from_n"] = co.get("gpu_faster_than_blst_model_from_n")
+        # the stated MODEL of BLST (not a measurement: BLST is not on the box): 400 us per set per core + 600 us per call, at this box's cores
+        cb["blst_model_vps"] = cb.get("cores", 1) / 400e-6 if not cb.get("blst_on_this_box") else None
+        cb["value_over_blst_model"] = (out["value"] / cb["blst_model_vps"]) if cb.get("blst_model_vps") else None
+    mg = out.get("multi_gpu") or {}
+    for key, row in mg.items():
+        if isinstance(row, dict):
+            for k2, v2 in row.items():
+                if isinstance(v2, (int, float)):
+                    cfg["multi_%s_%s" % (key, k2)] = v2
+                elif isinstance(v2, dict):
+                    for k3, v3 in v2.items():
+                        if isinstance(v3, (int, float)):
+                            cfg["multi_%s_%s_%s" % (key, k2, k3)] = v3
 
 
 def one_caller_rows(m, cache, cache_tp, stream, d_sets, n, n_total, lo, hi, rnd, sharded_path):

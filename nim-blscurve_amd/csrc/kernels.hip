@@ -33,6 +33,7 @@
 #include "h2c.hpp"
 #include "pairing.hpp"
 #include "c12.hpp"
+#include "teamvm.hpp"
 
 using namespace bls;
 
@@ -544,13 +545,46 @@ __device__ __forceinline__ g2_jac clear_cofactor_g2_team(const g2_jac& p, const 
 }
 __device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return clear_cofactor_g2_team(p, team_lanes8{gbase, role}); }
 __device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
+// ------------------------------------------------------------------------------------------
+// Round 6: the same two jobs on the LANE-TEAM ENGINE (csrc/teamvm.hpp, programs from tools/teamvm.py): 16 lanes per message / pair, the
+// team's values in LDS slots, every formula a table of rounds (one Fp product per lane and round, quad-local linear combination folded
+// into the reduction).  No selects, no shuffles, nothing spilled.  Four teams per wave.
+// ------------------------------------------------------------------------------------------
+#define TVM_TABLE __device__
+#include "../build/teamvm_tables.inc"
+#if defined(__HIP_DEVICE_COMPILE__)
+// the team's region of a wave's LDS block, and the lane's place in its team
+template <uint32_t SLOTS>
+__device__ __forceinline__ tvm_lds_char* tvm_team_base(bls_u32x4* lds) {
+    return (tvm_lds_char*)(tvm_lds_u32x4*)lds + (threadIdx.x >> 4) * (SLOTS * TVM_SLOT_BYTES);
+}
+__device__ __forceinline__ bool tvm_slot_is_zero(const tvm_lds_char* team, uint32_t slot) {       // a slot holds |v| < 0.51 p: 0 mod p <=> every limb is 0
+    return fp_limbs_are_zero(tvm_ld(team, slot * TVM_SLOT_BYTES));
+}
+// cofactor clearing of the team's two mapped points (already in the slots X.. and BX.., partially reduced): H in X, Y, Z.  Returns false when
+// the result's Z is 0 - an exceptional case of the incomplete additions on the way (operand at infinity, P = +-Q: every later step keeps Z = 0)
+// or a genuine point at infinity: the caller recomputes with the complete formulas.
+__device__ __forceinline__ bool tvm_clear_cofactor(tvm_lds_char* team, uint32_t lane16) {
+    if (lane16 == 0) tvm_st(team, TVM_CLEAR_zero * TVM_SLOT_BYTES, fp_zero());
+    if (lane16 >= 12) {
+        const fp2 cx = fp2_from_const(k::PSI_CX), cy = fp2_from_const(k::PSI_CY);
+        tvm_st(team, (TVM_CLEAR_CX + (lane16 - 12)) * TVM_SLOT_BYTES, fp_select(lane16 < 14, fp_select(lane16 == 12, cx.c0, cx.c1), fp_select(lane16 == 14, cy.c0, cy.c1)));
+    }
+    static_assert(TVM_CLEAR_CY == TVM_CLEAR_CX + 2 && TVM_CLEAR_BX == TVM_CLEAR_X + 6, "slot order the prologue relies on");
+    tvm_run<false>(team, lane16, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, tvm_line_sink{});
+    return !(tvm_slot_is_zero(team, TVM_CLEAR_Z) & tvm_slot_is_zero(team, TVM_CLEAR_Z + 1));
+}
+#endif
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
 // their independent products over roles 0..2.  Every group of 8 lanes does the same work.
 __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, xmd32_consts xc, uint4* __restrict__ H, size_t stride, size_t slot) {
-    const uint32_t role = threadIdx.x & 7u, gbase = threadIdx.x & ~7u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
+    const uint32_t lane16 = threadIdx.x & 15u;                      // every team of 16 lanes does the same work
+    tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
 #ifdef BLS_TAIL_CLOCK
-    unsigned long long ts[6];
+    unsigned long long ts[5];
     ts[0] = __builtin_amdgcn_s_memtime();
 #endif
     fp2 u0, u1;
@@ -565,27 +599,34 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
 #ifdef BLS_TAIL_CLOCK
     ts[1] = __builtin_amdgcn_s_memtime();
 #endif
-    g2_jac qs = sswu_g2(fp2_select(role == 1, u1, u0));
+    g2_jac qs = sswu_g2(fp2_select(lane16 == 1, u1, u0));           // the two maps side by side in lanes 0 and 1 of the team
 #ifdef BLS_TAIL_CLOCK
     ts[2] = __builtin_amdgcn_s_memtime();
 #endif
     g2_jac q = iso3_g2(qs);
-    g2_jac q0{fp2_from_role(q.x, gbase, 0), fp2_from_role(q.y, gbase, 0), fp2_from_role(q.z, gbase, 0)};
-    g2_jac q1{fp2_from_role(q.x, gbase, 1), fp2_from_role(q.y, gbase, 1), fp2_from_role(q.z, gbase, 1)};
+    if (lane16 < 2) {                                               // q0 -> the engine's slots X, Y, Z; q1 -> BX, BY, BZ
+        const uint32_t s0 = (TVM_CLEAR_X + 6 * lane16) * TVM_SLOT_BYTES;
+        tvm_st(team, s0, fp_reduce(q.x.c0)); tvm_st(team, s0 + 64, fp_reduce(q.x.c1));
+        tvm_st(team, s0 + 128, fp_reduce(q.y.c0)); tvm_st(team, s0 + 192, fp_reduce(q.y.c1));
+        tvm_st(team, s0 + 256, fp_reduce(q.z.c0)); tvm_st(team, s0 + 320, fp_reduce(q.z.c1));
+    }
 #ifdef BLS_TAIL_CLOCK
     ts[3] = __builtin_amdgcn_s_memtime();
 #endif
-    const team_lanes16 team{threadIdx.x & ~15u, threadIdx.x & 15u};      // the addition and the cofactor chain on quarter products (16 lanes per team)
-    g2_jac sum = jac_add_team(q0, q1, team);
+    const bool ok = tvm_clear_cofactor(team, lane16);               // q0 + q1 and the cofactor clearing on the lane-team engine
 #ifdef BLS_TAIL_CLOCK
     ts[4] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) printf("k_hash_one ticks: hash_to_field %llu  sswu %llu  isogeny+store %llu  add+cofactor (team engine) %llu\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
 #endif
-    g2_jac h = clear_cofactor_g2_team(sum, team);
-#ifdef BLS_TAIL_CLOCK
-    ts[5] = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) printf("k_hash_one ticks: hash_to_field %llu  sswu %llu  isogeny+gather %llu  add %llu  cofactor %llu\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
+    if (ok) {
+        if (threadIdx.x < 6 && blockIdx.x == 0) soa_st(H, stride, threadIdx.x, slot, tvm_ld(team, (TVM_CLEAR_X + threadIdx.x) * TVM_SLOT_BYTES));
+    } else {                                                        // wave-uniform (every team computed the same): the complete formulas on one lane
+        const uint32_t gbase = threadIdx.x & ~15u;
+        g2_jac q0{fp2_from_role(q.x, gbase, 0), fp2_from_role(q.y, gbase, 0), fp2_from_role(q.z, gbase, 0)};
+        g2_jac q1{fp2_from_role(q.x, gbase, 1), fp2_from_role(q.y, gbase, 1), fp2_from_role(q.z, gbase, 1)};
+        if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, clear_cofactor_g2(jac_add(q0, q1)));
+    }
 #endif
-    if (threadIdx.x == 0 && blockIdx.x == 0) soa_st_g2(H, stride, slot, h);
 }
 // batch form for batches that would not fill the chip with one lane per message: 8 lanes per message, or 16 (quarter products, team_lanes16) while
 // 16 lanes per message still fit the chip's one-per-SIMD wave slots (<= 4 096 messages)
@@ -604,6 +645,51 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restric
         h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
     }
     if (live && role == 0) soa_st_g2(H, stride, i, h);
+}
+
+// batches that leave wave slots free at 16 lanes per message (k_hash_clear_coop's job)
+__global__ void __launch_bounds__(WAVE) k_team_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
+    const uint32_t lane16 = threadIdx.x & 15u;
+    tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
+    uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool live = i < n;
+    if (!live) i = 0;                                             // idle teams recompute message 0 (no stores)
+    if (lane16 < 12)                                              // plane j of point 2 i + (0 | 1) -> slots X .. Z | BX .. BZ
+        tvm_st(team, (TVM_CLEAR_X + lane16) * TVM_SLOT_BYTES, fp_reduce(soa_ld(M, mstride, lane16 % 6, 2 * (size_t)i + lane16 / 6)));
+    (void)tvm_clear_cofactor(team, lane16);
+    // Z = 0 marks an exceptional case of the incomplete additions (or a true point at infinity): k_clear_fix, launched behind this kernel, finds
+    // such messages by their Z and recomputes them with the complete formulas - in a kernel of its own, so that this one keeps the engine's
+    // ~110 registers (the complete formulas need all 512) and several waves fit a SIMD
+    if (live && lane16 < 6) soa_st(H, stride, lane16, i, tvm_ld(team, (TVM_CLEAR_X + lane16) * TVM_SLOT_BYTES));
+#endif
+}
+__global__ void __launch_bounds__(WAVE) k_clear_fix(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fp2 z = soa_ld2(H, stride, 4, i);                       // stored partially reduced: 0 mod p <=> every limb is 0
+    if (!(fp_limbs_are_zero(z.c0) & fp_limbs_are_zero(z.c1))) return;
+    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
+    soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
+}
+// the Miller lines of FEW pairs (k_lines_coop's job): pairs first .. first + count - 1 -> the step-major line store
+__global__ void __launch_bounds__(WAVE) k_team_lines(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
+                                                     uint4* __restrict__ lines) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 lds[4 * TVM_LINES_SLOTS * 4];
+    const uint32_t lane16 = threadIdx.x & 15u;
+    tvm_lds_char* team = tvm_team_base<TVM_LINES_SLOTS>(lds);
+    uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool live = i < count;
+    i = first + (live ? i : 0);
+    static_assert(TVM_LINES_PY == TVM_LINES_PX + 1 && TVM_LINES_PZ == TVM_LINES_PX + 2 && TVM_LINES_QX == TVM_LINES_PX + 3, "slot order the prologue relies on");
+    if (lane16 < 3) tvm_st(team, (TVM_LINES_PX + lane16) * TVM_SLOT_BYTES, fp_reduce(soa_ld(P, stride, lane16, i)));
+    else if (lane16 < 9) tvm_st(team, (TVM_LINES_PX + lane16) * TVM_SLOT_BYTES, fp_reduce(soa_ld(H, stride, lane16 - 3, i)));
+    else if (lane16 == 9) tvm_st(team, TVM_LINES_zero * TVM_SLOT_BYTES, fp_zero());
+    const bool skip = tvm_slot_is_zero(team, TVM_LINES_PZ) | (tvm_slot_is_zero(team, TVM_LINES_QZ) & tvm_slot_is_zero(team, TVM_LINES_QZ + 1));
+    tvm_run<true>(team, lane16, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, tvm_line_sink{lines, stride, (size_t)i, live, skip});
+#endif
 }
 
 // G1 arithmetic has a small live set (a Jacobian point is 42 registers): 256 registers, two waves per SIMD, which fill each

@@ -1,4 +1,5 @@
-"""k_hash_clear (round 5: one hand-allocated assembly statement, tools/gen_clear_asm.py) on the device, through the test hook
+"""k_hash_clear (round 5: one hand-allocated assembly statement, tools/gen_clear_asm.py) and the lane-team engine's cofactor clearing (round 6:
+k_team_clear + k_clear_fix, csrc/teamvm.hpp; a latency-mode context takes it) on the device, through the test hook
 mi355_bls_debug_g2_clear_cofactor: H = clear_cofactor(q0 + q1) for pairs of arbitrary points of E2 against the oracle - including the inputs
 no hash produces and the loop does NOT handle itself (it flags them and the kernel recomputes the lane with the complete formulas): points at
 infinity, q0 == q1, q0 == -q1.  Reference: the cofactor clearing of hash-to-G2 (blst_abi.nim:383, RFC 9380 G.3)."""
@@ -29,7 +30,8 @@ def _jac_bytes(p, z):
     return b"".join(o.fp_to_mont_bytes(c) for c in (x[0], x[1], y[0], y[1], z[0], z[1]))
 
 
-def test_clear_cofactor_of_arbitrary_pairs(m):
+@pytest.mark.parametrize("mode", ["throughput", "latency"])
+def test_clear_cofactor_of_arbitrary_pairs(m, mode):
     rng = random.Random(3)
 
     def e2_point():          # a point of E2(Fp2), generally outside G2: what the SSWU map + isogeny produce
@@ -44,6 +46,7 @@ def test_clear_cofactor_of_arbitrary_pairs(m):
     blob = b"".join(_jac_bytes(p, z()) + _jac_bytes(q, z()) for p, q in pairs)
     out = ctypes.create_string_buffer(288 * len(pairs))
     cache = m.BatchedBLSVerifierCache.init(max_sets=128)
+    cache.set_cooperative(mode == "latency")        # latency: the lane-team engine; throughput: k_hash_clear
     assert m._check(m.lib().mi355_bls_debug_g2_clear_cofactor(cache._h, blob, len(pairs), out)) == 0
     for i, (p, q) in enumerate(pairs):
         got = g2_jac_to_affine(out.raw[288 * i:288 * i + 288])
