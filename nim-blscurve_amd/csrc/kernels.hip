@@ -316,7 +316,10 @@ __global__ void __launch_bounds__(WAVE) k_blind_many(const uint8_t* __restrict__
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
+#ifndef BLS_HASHMAP_WPS
+#define BLS_HASHMAP_WPS 2
+#endif
+__global__ void __launch_bounds__(WAVE, BLS_HASHMAP_WPS) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
                                                          size_t mstride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
     if (i >= n) return;
@@ -568,7 +571,7 @@ __device__ __forceinline__ bool tvm_clear_cofactor(tvm_lds_char* team, uint32_t 
     if (lane16 == 0) tvm_st(team, TVM_CLEAR_zero * TVM_SLOT_BYTES, fp_zero());
     if (lane16 >= 12) {
         const fp2 cx = fp2_from_const(k::PSI_CX), cy = fp2_from_const(k::PSI_CY);
-        tvm_st(team, (TVM_CLEAR_CX + (lane16 - 12)) * TVM_SLOT_BYTES, fp_select(lane16 < 14, fp_select(lane16 == 12, cx.c0, cx.c1), fp_select(lane16 == 14, cy.c0, cy.c1)));
+        tvm_st(team, (TVM_CLEAR_CX + (lane16 - 12)) * TVM_SLOT_BYTES, fp_reduce(fp_select(lane16 < 14, fp_select(lane16 == 12, cx.c0, cx.c1), fp_select(lane16 == 14, cy.c0, cy.c1))));
     }
     static_assert(TVM_CLEAR_CY == TVM_CLEAR_CX + 2 && TVM_CLEAR_BX == TVM_CLEAR_X + 6, "slot order the prologue relies on");
     tvm_run<false>(team, lane16, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, tvm_line_sink{});
@@ -648,7 +651,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restric
 }
 
 // batches that leave wave slots free at 16 lanes per message (k_hash_clear_coop's job)
-__global__ void __launch_bounds__(WAVE) k_team_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+__device__ __forceinline__ void team_clear_body(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
     const uint32_t lane16 = threadIdx.x & 15u;
@@ -661,9 +664,21 @@ __global__ void __launch_bounds__(WAVE) k_team_clear(const uint4* __restrict__ M
     (void)tvm_clear_cofactor(team, lane16);
     // Z = 0 marks an exceptional case of the incomplete additions (or a true point at infinity): k_clear_fix, launched behind this kernel, finds
     // such messages by their Z and recomputes them with the complete formulas - in a kernel of its own, so that this one keeps the engine's
-    // ~110 registers (the complete formulas need all 512) and several waves fit a SIMD
+    // ~100 registers (the complete formulas need all 512) and several waves fit a SIMD
     if (live && lane16 < 6) soa_st(H, stride, lane16, i, tvm_ld(team, (TVM_CLEAR_X + lane16) * TVM_SLOT_BYTES));
 #endif
+}
+// Two forms of each engine kernel, same code.  The plain one: ~100 registers, a SIMD takes several waves - for grids beyond one wave per SIMD.
+// The SPREAD one declares a whole SIMD's register file (amdgpu_waves_per_eu(1, 1): the register count in the kernel descriptor is raised to
+// what keeps a second wave out), for grids of at most one wave per SIMD: the dispatcher fills a CU up to its limits before it opens the
+// next, and two latency-bound waves that share a SIMD take twice as long (4 096 messages: 1.19 ms instead of 0.66).  An LDS pad did the
+// same until a kernel of the fork stream held LDS on the CU - then the fourth wave no longer fit and started a second round.
+__global__ void __launch_bounds__(WAVE) k_team_clear(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    team_clear_body(M, mstride, n, H, stride);
+}
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_clear_spread(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    team_clear_body(M, mstride, n, H, stride);
 }
 __global__ void __launch_bounds__(WAVE) k_clear_fix(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,8 +689,8 @@ __global__ void __launch_bounds__(WAVE) k_clear_fix(const uint4* __restrict__ M,
     soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
 }
 // the Miller lines of FEW pairs (k_lines_coop's job): pairs first .. first + count - 1 -> the step-major line store
-__global__ void __launch_bounds__(WAVE) k_team_lines(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
-                                                     uint4* __restrict__ lines) {
+__device__ __forceinline__ void team_lines_body(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
+                                                uint4* __restrict__ lines) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[4 * TVM_LINES_SLOTS * 4];
     const uint32_t lane16 = threadIdx.x & 15u;
@@ -690,6 +705,14 @@ __global__ void __launch_bounds__(WAVE) k_team_lines(const uint4* __restrict__ P
     const bool skip = tvm_slot_is_zero(team, TVM_LINES_PZ) | (tvm_slot_is_zero(team, TVM_LINES_QZ) & tvm_slot_is_zero(team, TVM_LINES_QZ + 1));
     tvm_run<true>(team, lane16, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, tvm_line_sink{lines, stride, (size_t)i, live, skip});
 #endif
+}
+__global__ void __launch_bounds__(WAVE) k_team_lines(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
+                                                     uint4* __restrict__ lines) {
+    team_lines_body(P, H, first, count, stride, lines);
+}
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_lines_spread(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride, uint4* __restrict__ lines) {
+    team_lines_body(P, H, first, count, stride, lines);
 }
 
 // G1 arithmetic has a small live set (a Jacobian point is 42 registers): 256 registers, two waves per SIMD, which fill each
@@ -709,8 +732,8 @@ __device__ __forceinline__ uint32_t pkmul_asm(uint64_t r, uint8_t* table, uint32
     return flag;
 }
 #endif
-__global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
-                                                   size_t stride, uint32_t* __restrict__ flags, uint8_t* __restrict__ table) {
+__device__ __forceinline__ void pkmul_body(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
+                                           size_t stride, uint32_t* __restrict__ flags, uint8_t* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320);
@@ -732,6 +755,18 @@ __global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ s
 #endif
     g1_jac q = jac_mul_u64_w4_body(pk, r[i]);
     soa_st_g1(P, stride, i, q);
+}
+__global__ void __launch_bounds__(WAVE, 2) k_pkmul(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P,
+                                                   size_t stride, uint32_t* __restrict__ flags, uint8_t* __restrict__ table) {
+    pkmul_body(sets, n, r, P, stride, flags, table);
+}
+// The same kernel for grids of at most one wave per SIMD (latency mode, up to 65 536 keys): it declares a whole SIMD's register file, so the
+// dispatcher cannot put two of its waves on one SIMD while others are idle (4 096 keys: 64 waves landed on 32 SIMDs and took 1.38 ms instead
+// of 0.75 - and held those SIMDs against the cofactor clearing's waves behind it).
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_pkmul_spread(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P, size_t stride, uint32_t* __restrict__ flags,
+               uint8_t* __restrict__ table) {
+    pkmul_body(sets, n, r, P, stride, flags, table);
 }
 
 // ------------------------------------------------------------------------------------------
