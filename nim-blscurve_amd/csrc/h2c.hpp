@@ -269,35 +269,6 @@ BLS_MID Pt clear_cofactor_g2_with(const Pt& p, Park& park, DblRun&& dbl_run, Dbl
     }
     return res;
 }
-// The same clearing with the chain as ONE loop over the 63 bits (a doubling per iteration, an addition where the bit is set): the form
-// of rounds 1-3, kept for the kernels with a TEAM of lanes per point (k_hash_one, k_hash_clear_coop).  Their doubling is a handful of
-// team rounds inlined in place anyway, and the run form above made hipcc spill half as many registers again inside their dependent
-// chains (689 -> 1021, k_hash_clear_coop 1.17 -> 1.31 ms).
-template <class Pt, class Park, class Dbl, class AddIn, class Add>
-BLS_MID Pt clear_cofactor_g2_bits(const Pt& p, Park& park, Dbl&& dbl, AddIn&& add_in, Add&& add) {
-    Pt base = p, u = p, res = p;
-#pragma clang loop unroll(disable)
-    for (int pass = 0; pass < 2; pass++) {
-        park.put(base);
-        Pt acc = base;                                       // bit 63 of |x|
-#pragma clang loop unroll(disable)
-        for (int i = 62; i >= 0; i--) {
-            acc = dbl(acc);
-            if ((k::X_ABS >> i) & 1) acc = add_in(acc, park.get());
-        }
-        acc = jac_neg(acc);                                  // x < 0
-        if (pass == 0) {
-            Pt t2 = g2_psi(p);
-            u = add(g2_psi(g2_psi(dbl(p))), jac_neg(t2));                // psi^2(2P) - psi(P)
-            u = add(u, jac_neg(acc));                                    // - [x]P
-            u = add(u, jac_neg(p));                                      // - P
-            base = add(acc, t2);                                         // [x]P + psi(P)
-        } else {
-            res = add(u, acc);
-        }
-    }
-    return res;
-}
 // n >= 1 doublings with the point as a loop-carried value; ONE copy of the doubling in the loop (do-while: no peeled first iteration)
 template <class F, class M>
 BLS_MID jac<F> jac_dbl_n(const jac<F>& a, int n, const M& m) {

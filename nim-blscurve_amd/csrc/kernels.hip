@@ -403,14 +403,11 @@ __global__ void __launch_bounds__(WAVE) k_debug_to_soa(const uint32_t* __restric
     soa_st_g2(M, mstride, i, ld_g2_blst(in + (size_t)i * 72));
 }
 
-// arbitrary-length message (fastAggregateVerify / coreVerify shape): ONE message, so latency is all that matters.
-// A wave works on it cooperatively: the two SSWU maps run in lanes 0 and 1, and every G2 doubling of the cofactor
-// clearing (128 of them) spreads the independent products of its first two rounds over lanes 0..2
-// (3 multiplication times per doubling instead of 7).  Every lane holds the same points throughout.
-// lane-parallel jac_dbl inside a group of 8 lanes that all hold the same point (same formulas, carries and
-// reductions as curve.hpp's): roles 0..2 take the three independent products of each of the first two rounds
-// device teams: lanes gbase .. gbase + 7 hold the same values; roles 0.. take one product each of a round (ONE multiplier call
-// with per-lane operands), then every lane reads all results with wave shuffles.  Formulas: jac_dbl_team / miller_dbl_step_team.
+// Device teams of the compiled lane-cooperative formulas (curve.hpp jac_dbl_team / jac_add_team): lanes gbase .. gbase + 7 hold the same values;
+// roles 0.. take one product each of a round (ONE multiplier call with per-lane operands), then every lane reads all results with wave
+// shuffles.  Rounds 1-5 ran the latency path's hashing and Miller lines this way (k_hash_clear_coop, k_lines_coop, 8 or 16 lanes per item:
+// ~700 spilled registers, ~5 300 cycles per round); round 6 moved those to the lane-team engine below (csrc/teamvm.hpp).  What is left here
+// serves the doubling chains of the G2 Pippenger's window sums (dbl_coop).
 template <int CTRL>
 __device__ __forceinline__ fp fp_quad_perm(const fp& a) {
     fp r;
@@ -418,69 +415,6 @@ __device__ __forceinline__ fp fp_quad_perm(const fp& a) {
     for (int i = 0; i < FP_N; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], CTRL, 0xf, 0xf, true);
     return r;
 }
-// The same interface on SIXTEEN lanes (one DPP row) for the one-message kernel, whose whole wave serves one point: an Fp2 product is FOUR Fp products on four
-// lanes (role r: product r / 4, part r % 4 = a0 b0 | a1 b1 | a0 b1 | a1 b0), combined inside the quad with one DPP exchange (real = p0 - p1, imaginary = p2 + p3)
-// and partially reduced, so a round costs a 392-multiply-add Fp product instead of the 784 of a lazily reduced half (k_hash_one's mul rounds 4.6 k -> ~3 k cycles).
-// Squares are two Fp products already and keep the two-lanes-per-square form.  Results: |value| < 0.51 p, carried limbs - tighter than team_lanes8's.
-struct team_lanes16 {
-    uint32_t gbase, role;
-    __device__ __forceinline__ fp quarter(const fp2& a, const fp2& b) const {
-        const uint32_t part = role & 3;
-        const bool second = part == 1;
-        fp v = fp_mul(fp_select((part & 1) != 0, a.c1, a.c0), fp_select(part == 1 || part == 2, b.c1, b.c0));
-        fp w = fp_quad_perm<0xb1>(v);                                      // the partner's product: parts 0 <-> 1, 2 <-> 3
-        fp d = fp_sub_nc(fp_select(second, w, v), fp_select(second, v, w));  // p0 - p1 in both lanes of the first pair
-        return fp_reduce(fp_select(part >= 2, fp_add_nc(v, w), d));
-    }
-    __device__ __forceinline__ fp2 gatherq(const fp& v, uint32_t q) const { return fp2{fp_from_role(v, gbase, 4 * q), fp_from_role(v, gbase, 4 * q + 2)}; }
-    __device__ __forceinline__ fp2 pick4(const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3) const {
-        const uint32_t q = role >> 2;
-        return fp2_select(q < 2, fp2_select(q == 0, a0, a1), fp2_select(q == 2, a2, a3));
-    }
-    __device__ __forceinline__ void mul4(fp2& r0, fp2& r1, fp2& r2, fp2& r3, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2,
-                                         const fp2& a3, const fp2& b3) const {
-        fp v = quarter(pick4(a0, a1, a2, a3), pick4(b0, b1, b2, b3));
-        r0 = gatherq(v, 0); r1 = gatherq(v, 1); r2 = gatherq(v, 2); r3 = gatherq(v, 3);
-    }
-    __device__ __forceinline__ void mul3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1, const fp2& a2, const fp2& b2) const {
-        fp v = quarter(pick4(a0, a1, a2, a2), pick4(b0, b1, b2, b2));
-        r0 = gatherq(v, 0); r1 = gatherq(v, 1); r2 = gatherq(v, 2);
-    }
-    __device__ __forceinline__ void mul2(fp2& r0, fp2& r1, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1) const {
-        const bool first = (role >> 2) == 0;
-        fp v = quarter(fp2_select(first, a0, a1), fp2_select(first, b0, b1));
-        r0 = gatherq(v, 0); r1 = gatherq(v, 1);
-    }
-    __device__ __forceinline__ fp2 mul1(const fp2& a, const fp2& b) const { return gatherq(quarter(a, b), 0); }
-    // squares: role r < 6 takes half r % 2 of square r / 2, as in team_lanes8
-    __device__ __forceinline__ fp half_sqr(const fp2& a) const {
-        const bool im = (role & 1) != 0;
-        return fp_mul(fp_select(im, fp_dbl_nc(a.c0), fp_add_nc(a.c0, a.c1)), fp_select(im, a.c1, fp_sub_nc(a.c0, a.c1)));
-    }
-    __device__ __forceinline__ fp2 gather2(const fp& v, uint32_t q) const { return fp2{fp_from_role(v, gbase, 2 * q), fp_from_role(v, gbase, 2 * q + 1)}; }
-    __device__ __forceinline__ void sqr3(fp2& r0, fp2& r1, fp2& r2, const fp2& a0, const fp2& a1, const fp2& a2) const {
-        const uint32_t q = role >> 1;
-        fp v = half_sqr(fp2_select(q == 0, a0, fp2_select(q == 1, a1, a2)));
-        r0 = gather2(v, 0); r1 = gather2(v, 1); r2 = gather2(v, 2);
-    }
-    __device__ __forceinline__ void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const {
-        fp v = half_sqr(fp2_select((role >> 1) == 0, a0, a1));
-        r0 = gather2(v, 0); r1 = gather2(v, 1);
-    }
-    // five squares = ten halves on ten lanes: ONE Fp product time (team_lanes8: a whole Fp2 square, two products, on each of five lanes)
-    __device__ __forceinline__ void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
-        const uint32_t q = role >> 1;
-        fp v = half_sqr(fp2_select(q == 0, a0, fp2_select(q == 1, a1, fp2_select(q == 2, a2, fp2_select(q == 3, a3, a4)))));
-        r0 = gather2(v, 0); r1 = gather2(v, 1); r2 = gather2(v, 2); r3 = gather2(v, 3); r4 = gather2(v, 4);
-    }
-    __device__ __forceinline__ void fpmul6(fp (&r)[6], const fp (&a)[6], const fp (&b)[3]) const {
-        fp xa = fp_select(role == 0, a[0], fp_select(role == 1, a[1], fp_select(role == 2, a[2], fp_select(role == 3, a[3], fp_select(role == 4, a[4], a[5])))));
-        fp xb = fp_select(role < 2, b[0], fp_select(role < 4, b[1], b[2]));
-        fp v = fp_mul(xa, xb);
-#pragma unroll
-        for (int i = 0; i < 6; i++) r[i] = fp_from_role(v, gbase, (uint32_t)i);
-    }
-};
 struct team_lanes8 {
     uint32_t gbase, role;
     // An Fp2 product is two independent dot products, an Fp2 square two independent Fp products: SIX lanes take one HALF each
@@ -538,16 +472,6 @@ struct team_lanes8 {
     }
 };
 __device__ __forceinline__ g2_jac g2_dbl_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return jac_dbl_team(p, team_lanes8{gbase, role}); }
-// clear_cofactor_g2 (h2c.hpp) with the two 63-doubling chains lane-parallel; the chain accumulator stays in registers (inlined
-// loop), the base point waits in the registers of the team (every lane holds it anyway)
-template <class Team>
-__device__ __forceinline__ g2_jac clear_cofactor_g2_team(const g2_jac& p, const Team& team) {
-    g2_park_regs park;
-    auto add = [&](const g2_jac& a, const g2_jac& b) { return jac_add_team(a, b, team); };
-    return clear_cofactor_g2_bits(p, park, [&](const g2_jac& a) { return jac_dbl_team(a, team); }, add, add);
-}
-__device__ __forceinline__ g2_jac clear_cofactor_g2_coop(const g2_jac& p, uint32_t gbase, uint32_t role) { return clear_cofactor_g2_team(p, team_lanes8{gbase, role}); }
-__device__ __forceinline__ g2_jac g2_add_coop(const g2_jac& a, const g2_jac& b, uint32_t gbase, uint32_t role) { return jac_add_team(a, b, team_lanes8{gbase, role}); }
 // ------------------------------------------------------------------------------------------
 // Round 6: the same two jobs on the LANE-TEAM ENGINE (csrc/teamvm.hpp, programs from tools/teamvm.py): 16 lanes per message / pair, the
 // team's values in LDS slots, every formula a table of rounds (one Fp product per lane and round, quad-local linear combination folded
@@ -631,26 +555,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
     }
 #endif
 }
-// batch form for batches that would not fill the chip with one lane per message: 8 lanes per message, or 16 (quarter products, team_lanes16) while
-// 16 lanes per message still fit the chip's one-per-SIMD wave slots (<= 4 096 messages)
-template <int L>
-__global__ void __launch_bounds__(WAVE) k_hash_clear_coop(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
-    const uint32_t role = threadIdx.x & (L - 1), gbase = threadIdx.x & ~(uint32_t)(L - 1);
-    uint32_t i = blockIdx.x * (WAVE / L) + (threadIdx.x / L);
-    bool live = i < n;
-    if (!live) i = 0;
-    g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
-    g2_jac h;
-    if (L == 16) {
-        const team_lanes16 team{gbase, role};
-        h = clear_cofactor_g2_team(jac_add_team(q0, q1, team), team);
-    } else {
-        h = clear_cofactor_g2_coop(g2_add_coop(q0, q1, gbase, role), gbase, role);
-    }
-    if (live && role == 0) soa_st_g2(H, stride, i, h);
-}
-
-// batches that leave wave slots free at 16 lanes per message (k_hash_clear_coop's job)
+// batches that leave wave slots free at 16 lanes per message
 __device__ __forceinline__ void team_clear_body(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
@@ -688,7 +593,7 @@ __global__ void __launch_bounds__(WAVE) k_clear_fix(const uint4* __restrict__ M,
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
     soa_st_g2(H, stride, i, clear_cofactor_g2(jac_add(q0, q1)));
 }
-// the Miller lines of FEW pairs (k_lines_coop's job): pairs first .. first + count - 1 -> the step-major line store
+// the Miller lines of FEW pairs: pairs first .. first + count - 1 -> the step-major line store
 __device__ __forceinline__ void team_lines_body(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
                                                 uint4* __restrict__ lines) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -767,49 +672,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)
 k_pkmul_spread(const uint8_t* __restrict__ sets, uint32_t n, const uint64_t* __restrict__ r, uint4* __restrict__ P, size_t stride, uint32_t* __restrict__ flags,
                uint8_t* __restrict__ table) {
     pkmul_body(sets, n, r, P, stride, flags, table);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_lines_coop: the Miller lines of FEW pairs (up to 8 per wave): 8 lanes share one pair and split the independent
-// products of every doubling step (the 63 of the 68 steps): 5 squarings, then 2 squarings, then 2 products, then the
-// 6 Fp products of the line scaling, each group as ONE multiplier call with per-lane operands - about 4 multiplication
-// times per step instead of 15.  Same formulas, carries and reductions as miller_dbl_step; the 5 addition steps likewise
-// (miller_add_step_team: six rounds).  Used when the pairs would not fill the chip anyway (latency: 2.3 -> ~0.8 ms).
-// ------------------------------------------------------------------------------------------
-template <int L> struct team_of { typedef team_lanes8 type; };
-template <> struct team_of<16> { typedef team_lanes16 type; };
-// L = 8 lanes per pair, or 16 (team_lanes16: quarter products, ten half squares in one round) while the pairs leave half the chip's wave slots free
-template <int L>
-__global__ void __launch_bounds__(WAVE) k_lines_coop(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
-                                                     uint4* __restrict__ lines) {
-    const uint32_t role = threadIdx.x & (L - 1), gbase = threadIdx.x & ~(uint32_t)(L - 1);
-    const typename team_of<L>::type team{gbase, role};
-    uint32_t i = blockIdx.x * (WAVE / L) + (threadIdx.x / L);
-    bool live = i < count;
-    i = first + (live ? i : 0);                                  // idle groups recompute pair `first` (no stores)
-    g1_jac pj = soa_ld_g1(P, stride, i);
-    g2_jac qj = soa_ld_g2(H, stride, i);
-    bool skip = jac_is_inf(pj) | jac_is_inf(qj);
-    g1_pre p = g1_precompute(pj);
-    g2_proj q = g2_to_proj(qj);
-    q = g2_proj{fp2_reduce(q.x), fp2_reduce(q.y), fp2_reduce(q.z)};
-    g2_proj t = q;
-    int sidx = 0;
-    auto sink = [&](const line_t& l0) {
-        if (live && role == 0) {
-            line_t l = skip ? line_one() : l0;
-            uint4* b = lines + (size_t)sidx * 24 * stride;
-            soa_st2(b, stride, 0, i, l.l0);
-            soa_st2(b, stride, 2, i, l.l1);
-            soa_st2(b, stride, 4, i, l.l2);
-        }
-        sidx++;
-    };
-#pragma clang loop unroll(disable)
-    for (int bit = 62; bit >= 0; bit--) {
-        sink(miller_dbl_step_team(t, p, team));
-        if ((k::X_ABS >> bit) & 1) sink(miller_add_step_team(t, q, p, team));
-    }
 }
 
 // lines[s] : 6 fp planes (l0.c0,l0.c1,l1.c0,l1.c1,l2.c0,l2.c1), step-major

@@ -84,44 +84,6 @@ BLS_MID line_t miller_dbl_step_m(g2_proj& t, const g1_pre& p, const M& m) {
 }
 BLS_MID line_t miller_dbl_step(g2_proj& t, const g1_pre& p) { return miller_dbl_step_m(t, p, mul_shared{}); }
 
-// The same step with a team of lanes per pair (see jac_dbl_team, curve.hpp): five squarings, then two, then two products, then the
-// six Fp products of the line scaling, each group as one multiplier call.  Formula, carries and reductions are miller_dbl_step's.
-struct team_solo_miller : team_solo {
-    BLS_HD void sqr5(fp2& r0, fp2& r1, fp2& r2, fp2& r3, fp2& r4, const fp2& a0, const fp2& a1, const fp2& a2, const fp2& a3, const fp2& a4) const {
-        r0 = fp2_sqr(a0); r1 = fp2_sqr(a1); r2 = fp2_sqr(a2); r3 = fp2_sqr(a3); r4 = fp2_sqr(a4);
-    }
-    BLS_HD void sqr2(fp2& r0, fp2& r1, const fp2& a0, const fp2& a1) const { r0 = fp2_sqr(a0); r1 = fp2_sqr(a1); }
-    BLS_HD void mul2(fp2& r0, fp2& r1, const fp2& a0, const fp2& b0, const fp2& a1, const fp2& b1) const { r0 = fp2_mul(a0, b0); r1 = fp2_mul(a1, b1); }
-    // r[i] = a[i] * b[i / 2]   (three Fp2 values scaled by three Fp factors)
-    BLS_HD void fpmul6(fp (&r)[6], const fp (&a)[6], const fp (&b)[3]) const {
-        for (int i = 0; i < 6; i++) r[i] = fp_mul(a[i], b[i >> 1]);
-    }
-};
-template <class Team>
-BLS_MID line_t miller_dbl_step_team(g2_proj& t, const g1_pre& p, const Team& team) {
-    fp2 B, C, X2, S1, S2;
-    team.sqr5(B, C, X2, S1, S2, t.y, t.z, t.x, fp2_add(t.y, t.z), fp2_add(t.x, t.y));
-    fp2 C4 = fp2_dbl_nc(fp2_carry(fp2_dbl_nc(fp2_mul_xi_nc(C))));
-    fp2 E = fp2_reduce(fp2_add_nc(fp2_dbl_nc(C4), C4));
-    fp2 F = fp2_add_nc(fp2_dbl_nc(E), E);
-    fp2 H = fp2_carry(fp2_sub_nc(fp2_sub_nc(S1, B), C));
-    fp2 XY2 = fp2_carry(fp2_sub_nc(fp2_sub_nc(S2, X2), B));
-    fp2 E2, S;
-    team.sqr2(E2, S, E, fp2_carry(fp2_add_nc(B, F)));
-    fp2 E2x4 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(E2)));
-    fp2 x3, BH;
-    team.mul2(x3, BH, XY2, fp2_carry(fp2_sub_nc(B, F)), B, H);
-    fp2 y3 = fp2_reduce(fp2_sub_nc(S, fp2_add_nc(fp2_dbl_nc(E2x4), E2x4)));
-    fp2 z3 = fp2_carry(fp2_dbl_nc(fp2_dbl_nc(BH)));
-    t = g2_proj{x3, y3, z3};
-    fp2 BE = fp2_sub_nc(B, E);
-    fp r[6];
-    const fp a[6] = {BE.c0, BE.c1, X2.c0, X2.c1, H.c0, H.c1};
-    const fp b[3] = {p.z3, p.nxz3, p.y};
-    team.fpmul6(r, a, b);
-    return line_t{fp2{r[0], r[1]}, fp2{r[2], r[3]}, fp2{r[4], r[5]}};
-}
-
 // T <- T + Q (both homogeneous), returns the chord through T and Q evaluated at P, times (x2 - x1) Z1 Z2^2:
 //   (u X2 - v Y2)  -  u Z2 * xp v  +  v Z2 * yp vw,      u = Y2 Z1 - Y1 Z2,  v = X2 Z1 - X1 Z2
 BLS_MID line_t miller_add_step(g2_proj& t, const g2_proj& q, const g1_pre& p) {
@@ -140,34 +102,6 @@ BLS_MID line_t miller_add_step(g2_proj& t, const g2_proj& q, const g1_pre& p) {
     fp2 c2 = fp2_mul(v, q.z);
     t = g2_proj{x3, y3, z3};
     return line_t{fp2_mul_fp(c0, p.z3), fp2_neg(fp2_mul_fp(c1, p.xz)), fp2_mul_fp(c2, p.y)};
-}
-
-// The addition step with a team of lanes per pair: six rounds (four products each, then two, then the six Fp products of the line
-// scaling) instead of sixteen multiplications, two squarings and six Fp products in a row on every lane.  Formula, carries and
-// reductions are miller_add_step's.
-template <class Team>
-BLS_MID line_t miller_add_step_team(g2_proj& t, const g2_proj& q, const g1_pre& p, const Team& team) {
-    fp2 Y1Z2, X1Z2, Y2Z1, X2Z1;
-    team.mul4(Y1Z2, X1Z2, Y2Z1, X2Z1, t.y, q.z, t.x, q.z, q.y, t.z, q.x, t.z);
-    fp2 u = fp2_sub(Y2Z1, Y1Z2);
-    fp2 v = fp2_sub(X2Z1, X1Z2);
-    fp2 uu, vv, Z1Z2, uX2;
-    team.mul4(uu, vv, Z1Z2, uX2, u, u, v, v, t.z, q.z, u, q.x);
-    fp2 vY2, c1, c2, vvv;
-    team.mul4(vY2, c1, c2, vvv, v, q.y, u, q.z, v, q.z, v, vv);
-    fp2 R, uuZ, z3, vvvY;
-    team.mul4(R, uuZ, z3, vvvY, vv, X1Z2, uu, Z1Z2, vvv, Z1Z2, vvv, Y1Z2);
-    fp2 A = fp2_carry(fp2_sub_nc(fp2_sub_nc(uuZ, vvv), fp2_dbl_nc(R)));
-    fp2 x3, uRA;
-    team.mul2(x3, uRA, v, A, u, fp2_sub_nc(R, A));
-    fp2 y3 = fp2_reduce(fp2_sub_nc(uRA, vvvY));
-    fp2 c0 = fp2_carry(fp2_sub_nc(uX2, vY2));
-    t = g2_proj{x3, y3, z3};
-    fp r[6];
-    const fp a[6] = {c0.c0, c0.c1, c1.c0, c1.c1, c2.c0, c2.c1};
-    const fp b[3] = {p.z3, p.xz, p.y};
-    team.fpmul6(r, a, b);
-    return line_t{fp2{r[0], r[1]}, fp2_neg(fp2{r[2], r[3]}), fp2{r[4], r[5]}};
 }
 
 // Emits the 68 lines of pair (P, Q) through sink(step, line).  A pair with P or Q at infinity

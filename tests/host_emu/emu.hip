@@ -104,25 +104,6 @@ void emu_g2_sum_xyzz(const uint8_t* pts, uint32_t n, uint8_t* out) {
     for (uint32_t i = 0; i < n; i++) acc = xyzz_add_aff(acc, g2_aff_load(pts + 192 * i));
     g2_jac_store(out, jac_from_xyzz(acc));
 }
-// 68 lines of one pair with the team doubling step (additions as in miller_lines) against miller_lines itself: 1 = identical
-int emu_miller_lines_team_equal(const uint8_t* p144, const uint8_t* q288) {
-    g1_jac pj = g1_jac_load(p144);
-    g2_jac qj = g2_jac_load(q288);
-    line_t ref[N_LINES];
-    miller_lines(pj, qj, [&](int s, const line_t& l) { ref[s] = l; });
-    g1_pre p = g1_precompute(pj);
-    g2_proj q = g2_to_proj(qj);
-    q = g2_proj{fp2_reduce(q.x), fp2_reduce(q.y), fp2_reduce(q.z)};
-    g2_proj t = q;
-    int s = 0, same = 1;
-    auto eq = [&](const line_t& a, const line_t& b) { return fp2_eq(a.l0, b.l0) & fp2_eq(a.l1, b.l1) & fp2_eq(a.l2, b.l2); };
-    for (int bit = 62; bit >= 0; bit--) {
-        line_t l = miller_dbl_step_team(t, p, team_solo_miller{});
-        same &= eq(l, ref[s++]);
-        if ((k::X_ABS >> bit) & 1) { line_t a = miller_add_step_team(t, q, p, team_solo_miller{}); same &= eq(a, ref[s++]); }
-    }
-    return same;
-}
 void emu_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g1_jac_store(out, jac_add(g1_jac_load(a), g1_jac_load(b))); }
 void emu_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { g2_jac_store(out, jac_add(g2_jac_load(a), g2_jac_load(b))); }
 // n pairs of (P Jacobian 144 B, Q Jacobian 288 B) -> final_exp(miller) 576 B

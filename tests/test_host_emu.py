@@ -360,7 +360,6 @@ def test_team_formulas_equal_the_plain_ones(emu):
             a, b = call(emu, "emu_g1_dbl_team", P, outlen=144), call(emu, "emu_g1_dbl", P, outlen=144)
             assert g1_jac_to_affine(a) == g1_jac_to_affine(b)
             P = a
-        assert emu.emu_miller_lines_team_equal(P, Q) == 1
         # the team addition: general position (non-trivial Z on both sides), P + P, P + (-P), infinity on either side
         q2 = o.g2_mul(o.G2_GEN, rng.randrange(1, o.R))
         Q2 = call(emu, "emu_g2_dbl", g2_aff_to_jac_bytes(q2), outlen=288)
