@@ -79,7 +79,7 @@ def spawn_ranks(a):
     import subprocess
     n = a.gpus
     have = torch.cuda.device_count()                 # counts devices without initialising the GPU
-    if have < n and os.environ.get("BENCH_ALL_ON_DEVICE0") != "1":
+    if have < n and os.environ.get("BENCH_ALL_ON_DEVICE0") != "1" and os.environ.get("BENCH_FORCE_LOCAL0") != "1":
         sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) are visible\n" % (n, have))
         return 2
     ge.build(load=False)                             # compile once here, not N times in the ranks
@@ -450,8 +450,8 @@ def main():
     # BENCH_DIST_BACKEND=gloo + BENCH_ALL_ON_DEVICE0=1 is a TEST HOOK: it lets the N > 1 code path (sharding, exchange,
     # merge) run end to end on a box with a single GPU; real runs use RCCL ("nccl") with one GPU per rank.
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_ALL_ON_DEVICE0") == "1":
-        local = 0
+    if os.environ.get("BENCH_ALL_ON_DEVICE0") == "1" or os.environ.get("BENCH_FORCE_LOCAL0") == "1":
+        local = 0                # BENCH_FORCE_LOCAL0: TEST HOOK of the guard below (ranks on one device WITHOUT declaring the dry run)
     sharded_path = world > 1 or a.force_dist
     ctl = None
     if sharded_path:
@@ -475,6 +475,11 @@ def main():
         sys.exit(2)
     ceiling_live = measure_ceiling() if (rank == 0 and not a.no_ceiling) else None
     dinfo = dist_info(world, backend, ctl, dev) if sharded_path else None
+    if dinfo and world > 1 and not dinfo["all_on_device0_test_hook"] and dinfo["distinct_devices"] != world:
+        # a real N-GPU run whose ranks landed on fewer than N devices would report a scaling curve of one GPU: fail loudly instead
+        sys.stderr.write("bench.py: %d ranks but %d distinct devices (%s); set BENCH_ALL_ON_DEVICE0=1 only for the documented dry run\n"
+                         % (world, dinfo["distinct_devices"], dinfo["device_uuids"]))
+        sys.exit(2)
 
     n = a.batch
     run = ShardedRun(m, a, dev, local, rank, world, backend, ctl, n, sharded_path)
@@ -603,6 +608,16 @@ def main():
         del run, caches, d_sets
         torch.cuda.synchronize()
         multi = {"g1_msm": msm_rows_sharded(m, cache, dev, rank, world, backend, ctl, a.msm_log2)}
+        # STRONG scaling beside the weak headline (BASELINE's metric is quoted "at 1/2/4/8 MI355X"): ONE --batch-sized batch in all, batch / N
+        # tuples per GPU, same exchange and merge.  (Small shards are latency-bound: a GPU verifies 8 192 tuples in ~5.7 ms, 65 536 in ~13.)
+        ns = max(1, a.batch // world)
+        runs = ShardedRun(m, a, dev, local, rank, world, backend, ctl, ns, True)
+        ks = max(2, min(a.steps, 20)) if a.batch < 65536 else max(6, min(a.steps, 20))
+        dts = runs.timed(ks, min(3, a.warmup))
+        multi["batchVerify_strong"] = {"verifications_per_s": runs.n_total * ks / dts, "ms_per_step": dts / ks * 1e3, "global_batch": runs.n_total,
+                                       "tuples_per_gpu": ns, "steps": ks, "scaling": "strong", "exchange": runs.exchange}
+        runs.close()
+        del runs
         if world == 8:
             # BASELINE config 5: 2^20 tuples across 8 GPUs = 131 072 per GPU = twice the headline batch (the row follows --batch so that a
             # dry run of this code path with small batches stays cheap: tests/test_gpu_bench_multirank.py)

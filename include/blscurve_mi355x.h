@@ -396,6 +396,11 @@ size_t mi355_bls_debug_multi_enqueue_us(float* out, size_t cap);
  * low-latency and the least-work fold of the line products (a batch enqueued while this is zero has the chip to itself).  The tests
  * check that submit / wait / destroy keep it balanced. */
 int mi355_bls_debug_batches_in_flight(void);
+/* Which fold of the per-lane line products the LAST batch / shard call on this context enqueued: 1 = the low-latency form on the Fp12 engine
+ * (k_fold: latency-mode contexts, and any call enqueued while no other batch of the process was in flight), 0 = the least-work form
+ * (k_lineprod2: throughput-mode contexts with other batches in flight).  Same GT bytes either way; profiles and the bench line record it so
+ * that a kernel mix can be attributed.  Negative: bad argument. */
+int mi355_bls_last_fold_form(mi355_bls_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,7 @@ def lib():
         L.mi355_bls_p1s_add_device.argtypes = [vp, ctypes.c_char_p, vp, sz, sz, vp]
         L.mi355_bls_debug_fail_next_enqueue.argtypes = [vp]
         L.mi355_bls_debug_batches_in_flight.argtypes = []
+        L.mi355_bls_last_fold_form.argtypes = [vp]
         L.mi355_bls_debug_g2_clear_cofactor.argtypes = [vp, cp, sz, cp]
         L.mi355_bls_debug_multi_enqueue_us.argtypes = [ctypes.POINTER(ctypes.c_float), sz]
         L.mi355_bls_debug_multi_enqueue_us.restype = sz
@@ -233,6 +234,10 @@ class BatchedBLSVerifierCache:
         t = (ctypes.c_float * 4)()
         _check(lib().mi355_bls_last_kernel_timings(self._h, t))
         return dict(zip(["k_hash_map", "k_hash_clear", "k_lineprod", "k_lineprod2"], list(t)))
+
+    def fold_form(self):
+        """which fold of the line products the last batch call enqueued: 1 = the Fp12 engine (k_fold), 0 = k_lineprod2"""
+        return lib().mi355_bls_last_fold_form(self._h)
 
     # -- device-resident entry points --
     def verify_device(self, d_ptr, n, secureRandomBytes, stream=0):

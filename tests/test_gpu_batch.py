@@ -147,8 +147,8 @@ def test_parity_vs_c_oracle_at_scale(m, n, nt):
 
 
 def test_cooperative_and_plain_kernels_agree(m):
-    """Batches that do not fill the chip use 8 lanes per set by default; the one-lane-per-set kernels must give the same
-    H(m_i) points, GT value and verdict."""
+    """Batches that do not fill the chip run hashing and Miller lines on the lane-team engine by default (16 lanes per set, csrc/teamvm.hpp);
+    the one-lane-per-set kernels must give the same H(m_i) points, GT value and verdict."""
     import c_oracle as co
     n = 600
     rec = co.make_batch(n, seed=31337)
@@ -174,6 +174,9 @@ def test_cooperative_and_plain_kernels_agree(m):
     assert b.verify_device(d.data_ptr(), n, rnd) is True
     assert other.wait() is True
     assert b.fetch(4, 576) == st["gt"] and other.fetch(4, 576) == st["gt"]
+    # the choice is recorded per call (mi355_bls_last_fold_form): `other` was enqueued with nothing in flight -> engine fold; `b` (the
+    # one-lane-per-set context) behind it -> k_lineprod2; a latency-mode context always folds on the engine
+    assert other.fold_form() == 1 and b.fold_form() == 0 and a.fold_form() == 1
     for c in (a, b, other):
         c.close()
 

@@ -74,6 +74,10 @@ def test_eight_ranks_dry_run_on_one_gpu():
     c5 = d["multi_gpu"]["config5_shape_batchVerify"]
     assert c5["tuples_per_gpu"] == 8192 and c5["global_batch"] == 8 * 8192 and c5["verifications_per_s"] > 0
     assert d["multi_gpu"]["g1_msm"]["weak_2^14_per_gpu"]["points_total"] == 8 << 14
+    # the strong-scaling row beside the weak headline: one --batch-sized batch in all, batch / 8 per GPU
+    st = d["multi_gpu"]["batchVerify_strong"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 4096 and st["tuples_per_gpu"] == 512 and st["verifications_per_s"] > 0
+    assert d["scaling"] == "weak" and d["config"]["multi_batchVerify_strong_ms_per_step"] == st["ms_per_step"]      # repeated flat for the driver's record
     # what stands behind the N > 1 line (round-4 review): backend, world size and one device identity per rank, over the control group
     di = d["dist"]
     assert di["backend"] == "gloo" and di["is_rccl"] is False and di["world_size"] == 8 and len(di["device_uuids"]) == 8
@@ -84,6 +88,19 @@ def test_eight_ranks_dry_run_on_one_gpu():
     assert abs(rf["frac"] - 320 * 4096 / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-9
     assert set(rf["kernels"]) == {"k_hash_map", "k_hash_clear", "k_pkmul", "k_sig_bucket", "k_lines", "k_lineprod"}
     assert rf["int_mad"]["ceiling"]["measured_on_this_box"] is True and 0.5 < rf["int_mad"]["ceiling"]["frac_of_peak"] < 1.0
+
+
+def test_ranks_on_one_device_without_the_hook_fail_loudly():
+    """Two ranks that land on ONE device without BENCH_ALL_ON_DEVICE0 (what a mis-set LOCAL_RANK / visible-devices mask would do on a real
+    node): the run must refuse instead of reporting the scaling of one GPU as that of two."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env.pop("BENCH_ALL_ON_DEVICE0", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["BENCH_FORCE_LOCAL0"] = "1"          # test hook: every rank uses device 0 WITHOUT declaring the dry run
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64", "--no-cpu", "--no-aux"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode != 0 and "distinct devices" in p.stderr, p.stderr[-2000:]
 
 
 def test_a_dying_rank_fails_the_run():
