@@ -11,7 +11,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=${BLS_OUT:-libblscurve_mi355x.so}
 # up to date = the library was built from exactly these sources (content hash, not time stamps: a copy of the tree need not keep them)
-STAMP=$(cat csrc/* ../include/*.h tools/align_isa.py tools/gen_lineprod_asm.py tools/asmlib.py tools/gen_lines_asm.py tools/gen_clear_asm.py tools/gen_msm_asm.py tools/gen_pkmul_asm.py tools/teamvm.py build.sh | sha256sum | cut -d" " -f1)-$BLS_EXTRA_FLAGS-$BLS_NO_ALIGN
+STAMP=$(cat csrc/* ../include/*.h tools/align_isa.py tools/gen_lineprod_asm.py tools/asmlib.py tools/gen_lines_asm.py tools/gen_clear_asm.py tools/gen_msm_asm.py tools/gen_pkmul_asm.py tools/gen_pow_asm.py tools/teamvm.py build.sh | sha256sum | cut -d" " -f1)-$BLS_EXTRA_FLAGS-$BLS_NO_ALIGN
 if [ "$1" != "-f" ] && [ -f $OUT ] && [ "$(cat $OUT.stamp 2>/dev/null)" = "$STAMP" ]; then
   exit 0
 fi
@@ -29,6 +29,7 @@ python3 tools/gen_lines_asm.py -o $B/lines_asm.inc               # the 68-step M
 python3 tools/gen_clear_asm.py -o $B/clear_asm.inc               # k_hash_clear's body (cofactor clearing of hash-to-G2)
 python3 tools/gen_msm_asm.py -o $B/msm_asm.inc                   # the bucket accumulation of the G1 Pippenger MSM
 python3 tools/gen_pkmul_asm.py -o $B/pkmul_asm.inc               # [r]PK of the batch path
+python3 tools/gen_pow_asm.py -o $B/pow_asm.inc                   # a^((p-3)/4): the exponentiation behind every square root (hash-to-G2's SSWU maps, decompression)
 python3 tools/teamvm.py -o $B/teamvm_tables.inc                  # programs of the lane-team engine (csrc/teamvm.hpp): cofactor clearing, Miller walk
 aligned_build() {
   hipcc $FLAGS --cuda-device-only -S -o $B/dev.s csrc/kernels.hip || return 1

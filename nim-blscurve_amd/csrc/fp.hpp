@@ -726,7 +726,30 @@ BLS_HDN fp fp_inv(const fp& a) {
 }
 
 // a^((p-3)/4): for a QR this is 1/sqrt(a); for a non-residue (a*t)^2 = -a.
-BLS_HD fp fp_recip_sqrt_pow(const fp& a) { return fp_pow_sched(a, k::SW_PM3D4, k::SW_PM3D4_LEN); }
+// Device (round 6): ONE hand-allocated assembly statement (tools/gen_pow_asm.py -> build/pow_asm.inc): the exponent is the same for every lane, so the
+// 4-bit sliding-window schedule is unrolled into the code and the table of odd powers lives in registers (v60 .. v171) instead of the scratch memory
+// fp_pow_sched indexes it in; 172 VGPRs and no AGPRs, so the two-waves-per-SIMD kernels keep their occupancy.  Contract: |a| < 8 p, limbs of at most two
+// units (asserted by the host tracker below); result as fp_mul's: canonical limbs, |r| < 2 p.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_POW_NOASM)
+#include "../build/pow_asm.inc"
+// Expanded in place at every call site (a few per kernel), not an out-of-line function: the statement clobbers v0 .. v171, half of which the
+// calling convention makes a callee preserve - as a function it saved them in AGPRs, and in the unified register file of a 256-register kernel
+// those start behind the kernel's own allocation (k_hash_map: 288 registers = one wave per SIMD).
+__device__ __forceinline__ fp fp_recip_sqrt_pow(const fp& a) {
+    uint32_t a0 = a.l[0], a1 = a.l[1], a2 = a.l[2], a3 = a.l[3], a4 = a.l[4], a5 = a.l[5], a6 = a.l[6], a7 = a.l[7], a8 = a.l[8], a9 = a.l[9], a10 = a.l[10],
+             a11 = a.l[11], a12 = a.l[12], a13 = a.l[13];
+    asm volatile(BLS_POW_ASM_BODY
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13)
+                 :
+                 : BLS_POW_ASM_CLOBBERS);
+    return fp{{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+}
+#else
+BLS_HD fp fp_recip_sqrt_pow(const fp& a) {
+    BLS_REQUIRE(BLS_VB(a) <= 8 && BLS_LB(a) <= 2, "fp_recip_sqrt_pow: the device body's input contract");
+    return fp_pow_sched(a, k::SW_PM3D4, k::SW_PM3D4_LEN);
+}
+#endif
 
 // 48 little-endian bytes (blst_fp memory image) <-> fp   (host-side tests and byte-addressed inputs)
 BLS_HD fp fp_load_le(const uint8_t* p) {

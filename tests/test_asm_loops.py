@@ -131,3 +131,17 @@ def test_pkmul_text_is_one_statement():
     assert "#define BLS_PKMUL_ASM_BODY" in t and "#define BLS_PKMUL_ASM_CLOBBERS" in t
     assert "scratch_" not in t and '"a0"' not in t and '"v241"' in t and '"v242"' not in t      # VGPRs only, two waves per SIMD
     assert t.count("v_mad_i64_i32") < 7000          # the hot code (two shared bodies, the doubling, the addition's glue) stays near 40 KB
+
+
+def test_pow_chain_matches_python_pow():
+    """fp_recip_sqrt_pow's device body (round 6, tools/gen_pow_asm.py): a^((p-3)/4) through the whole unrolled 4-bit sliding-window schedule against
+    Python's pow, on a canonical residue, on 1, and on the widest input the contract allows (a limb-wise sum of two residues)."""
+    out = run("gen_pow_asm.py", "--selftest")
+    assert "selftest ok" in out
+    m = re.search(r"(\d+) squarings \+ (\d+) window products \+ 8 for the table; (\d+) VALU instructions, (\d+) multiply-adds", out)
+    nsq, nmul, valu, mads = map(int, m.groups())
+    assert nsq + 1 + 3 == 379 and nmul + 8 <= 86          # 379 doublings of the exponent in all (one in the table, the top window holds three bits)
+    assert mads / valu > 0.79
+    t = run("gen_pow_asm.py")
+    assert "#define BLS_POW_ASM_BODY" in t and "scratch_" not in t and "accvgpr" not in t       # the table in VGPRs: no AGPR, no memory
+    assert '"v171"' in t and '"v172"' not in t
