@@ -47,7 +47,7 @@ S_SQR, S_MUL, S_D3A, S_D3B, S_PREP, S_ADD, S_PSI, S_CHAIN = 54, 56, 58, 60, 62, 
 S_RET, S_RET2, S_RET3 = 70, 72, 74
 S_I, S_XA, S_T, S_GP, S_MSTR, S_HSTR, S_SSTR = 76, 78, 80, 82, 84, 85, 86
 S_MB, S_HB, S_SB = 88, 90, 92                    # bases (pairs): mapped points, output, scratch columns
-CLOBBER_S = (36, 94)
+CLOBBER_S = (36, 96)
 
 # psi constants (Montgomery images): cx = 1 / xi^((p-1)/3), cy = 1 / xi^((p-1)/2), xi = 1 + u   (tools/gen_constants.py PSI_CX, PSI_CY)
 def _f2mul(a, b):
@@ -274,6 +274,8 @@ def mem_op(a, triple, key, store, text):
 
 
 def lds_point(a, triple, store):
+    if TWO_WAVE:
+        return global_point(a, triple, ("lds",), store, S_SB3, S_SSTR, V_OFFH)
     t = []
     for s_, f in enumerate(triple):
         base = f.c0.r[0]
@@ -499,9 +501,52 @@ def selftest(walk=True, seed=5):
 
 
 # ---- text ---------------------------------------------------------------------------------------------------------------------------
+# TWO_WAVE (--two-wave, experiment of round 6): the same instruction lists for a kernel of 256 registers, two waves per SIMD.  Everything the
+# one-wave form keeps in AGPRs (the base point with its Z^2, Z^3, the addition's four parked intermediates: 252 words) and in LDS (the point that
+# outlives a chain) goes to global memory instead: "AGPR k" becomes row k of a wave-private block (256 contiguous bytes per row: one dword per
+# lane), the LDS slots become a third per-lane column of the scratch area.  The doubling loop - 126 of the kernel's 144 steps - touches none of
+# it.  The translation is textual (every accvgpr move becomes one dword load / store, a wait in front of and behind every run of loads); the
+# interpreter keeps running the AGPR form, which moves the same data.
+TWO_WAVE = False
+V_WOFF = 246                                   # this lane's byte offset inside a row of the wave's block (4 x lane)
+S_WB, S_WP, S_SB3 = 96, 98, 100                # the wave's block; the 4 KB page of it an instruction addresses; the third scratch column
+
+
 def text_of_list(ins):
     a = new_asm(); a.ins = ins
-    return a.text()
+    if not TWO_WAVE:
+        return a.text()
+    out, page, in_loads = [], None, False
+    for t in ins:
+        if t[0] == "hook":
+            continue
+        if t[0] in ("aread", "awrite"):
+            areg = t[2] if t[0] == "aread" else t[1]
+            vreg = t[1] if t[0] == "aread" else t[2]
+            byte = areg * 256
+            if byte // 4096 != page:
+                page = byte // 4096
+                out += ["s_add_u32 s%d, s%d, %d" % (S_WP, S_WB, page * 4096), "s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WB + 1)]
+            if t[0] == "aread":
+                if not in_loads:
+                    out.append("s_waitcnt vmcnt(0)")                  # earlier stores of this wave have landed
+                    in_loads = True
+                out.append("global_load_dword v%d, v%d, s[%d:%d] offset:%d" % (vreg, V_WOFF, S_WP, S_WP + 1, byte % 4096))
+            else:
+                if in_loads:
+                    out.append("s_waitcnt vmcnt(0)")
+                    in_loads = False
+                out.append("global_store_dword v%d, v%d, s[%d:%d] offset:%d" % (V_WOFF, vreg, S_WP, S_WP + 1, byte % 4096))
+            continue
+        if in_loads:
+            out.append("s_waitcnt vmcnt(0)")
+            in_loads = False
+        if t[0] == "call":
+            page = None                                                # a subroutine may move the page pointer
+        out += a.text_of(t).split("\n")
+    if in_loads:
+        out.append("s_waitcnt vmcnt(0)")
+    return out
 
 
 def kernel_text():
@@ -518,8 +563,12 @@ def kernel_text():
     T += ["s_mul_hi_u32 s%d, s%d, 24" % (S_T, S_SSTR), "s_mul_i32 s%d, s%d, 24" % (S_T + 1, S_SSTR),
           "s_add_u32 s%d, s%d, s%d" % (S_SB + 2, S_SB, S_T + 1), "s_addc_u32 s%d, s%d, s%d" % (S_SB + 3, S_SB + 1, S_T)]
     T += ["v_lshlrev_b32_e64 v%d, 5, %%7" % V_OFFM, "v_lshlrev_b32_e64 v%d, 4, %%7" % V_OFFH]
-    T += ["v_mbcnt_lo_u32_b32 v%d, -1, 0" % TMP, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (TMP, TMP), "v_lshlrev_b32_e64 v%d, 4, v%d" % (TMP, TMP),
-          "v_add_u32_e64 v%d, %%8, v%d" % (V_LDS, TMP)]
+    T += ["v_mbcnt_lo_u32_b32 v%d, -1, 0" % TMP, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (TMP, TMP)]
+    if TWO_WAVE:
+        # %9: this wave's block of 252 rows x 256 bytes (s pair); the third scratch column = + 48 rows
+        T += ["v_lshlrev_b32_e64 v%d, 2, v%d" % (V_WOFF, TMP), "s_mov_b64 s[%d:%d], %%9" % (S_WB, S_WB + 1),
+              "s_add_u32 s%d, s%d, s%d" % (S_SB3, S_SB + 2, S_T + 1), "s_addc_u32 s%d, s%d, s%d" % (S_SB3 + 1, S_SB + 3, S_T)]
+    T += ["v_lshlrev_b32_e64 v%d, 4, v%d" % (TMP, TMP), "v_add_u32_e64 v%d, %%8, v%d" % (V_LDS, TMP)]
     for name, sreg in SUB_ADDR.items():
         T += ["s_getpc_b64 s[%d:%d]" % (sreg, sreg + 1), ".Lcc_p%s%%=:" % name,
               "s_add_u32 s%d, s%d, (.Lcc_%s%%=-.Lcc_p%s%%=)&4294967295" % (sreg, sreg, name, name),
@@ -543,7 +592,10 @@ def kernel_text():
 
 
 def clobbers():
-    c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(*CLOBBER_S)] + ["vcc", "scc", "memory"]
+    if TWO_WAVE:
+        c = ["v%d" % i for i in range(CLOBBER_V)] + ["v%d" % V_WOFF] + ["s%d" % i for i in range(36, 102)] + ["vcc", "scc", "memory"]
+    else:
+        c = ["v%d" % i for i in range(CLOBBER_V)] + ["a%d" % i for i in range(256)] + ["s%d" % i for i in range(*CLOBBER_S)] + ["vcc", "scc", "memory"]
     return ", ".join('"%s"' % x for x in c)
 
 
@@ -552,15 +604,19 @@ def main():
     ap.add_argument("--selftest", action="store_true")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("-o", "--out")
+    ap.add_argument("--two-wave", action="store_true", help="the 256-register form (no AGPRs, no LDS): BLS_CLEAR2_ASM_BODY")
     a = ap.parse_args()
+    global TWO_WAVE
+    TWO_WAVE = a.two_wave
     if a.selftest:
         selftest(walk=not a.quick)
         return
     lines = [l if l.startswith(".L") else "\\t" + l for l in kernel_text()]
     txt = ("// GENERATED by nim-blscurve_amd/tools/gen_clear_asm.py -- do not edit.\n"
            "// operands: %0 flag out (v), %1 M (s pair), %2 M row stride bytes (s), %3 H (s pair), %4 H row stride bytes (s), %5 scratch columns (s pair), %6 their row stride (s), %7 lane index (v), %8 LDS address of three slots (s)\n"
-           "#define BLS_CLEAR_ASM_BODY \\\n" + "\n".join('    "%s\\n" \\' % l for l in lines) + "\n\n"
-           "#define BLS_CLEAR_ASM_CLOBBERS " + clobbers() + "\n")
+           + ("// two-wave form: %9 this wave's block of 252 rows x 256 bytes (s pair); %8 unused\n" if TWO_WAVE else "") +
+           "#define BLS_CLEAR%s_ASM_BODY \\\n" % ("2" if TWO_WAVE else "") + "\n".join('    "%s\\n" \\' % l for l in lines) + "\n\n"
+           "#define BLS_CLEAR%s_ASM_CLOBBERS " % ("2" if TWO_WAVE else "") + clobbers() + "\n")
     if a.out:
         open(a.out, "w").write(txt)
     else:
