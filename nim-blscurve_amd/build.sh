@@ -27,6 +27,7 @@ mkdir -p $B
 python3 tools/gen_lineprod_asm.py -o $B/lineprod_asm.inc         # the hand-allocated inner loop of k_lineprod (included by csrc/kernels.hip)
 python3 tools/gen_lines_asm.py -o $B/lines_asm.inc               # the 68-step Miller walk of k_lines (tools/asmlib.py)
 python3 tools/gen_clear_asm.py -o $B/clear_asm.inc               # k_hash_clear's body (cofactor clearing of hash-to-G2)
+python3 tools/gen_clear_asm.py --two-wave -o $B/clear2_asm.inc   # the same body for 256 registers (experiment builds with -DBLS_CLEAR_TWO_WAVE only)
 python3 tools/gen_msm_asm.py -o $B/msm_asm.inc                   # the bucket accumulation of the G1 Pippenger MSM
 python3 tools/gen_pkmul_asm.py -o $B/pkmul_asm.inc               # [r]PK of the batch path
 python3 tools/gen_pow_asm.py -o $B/pow_asm.inc                   # a^((p-3)/4): the exponentiation behind every square root (hash-to-G2's SSWU maps, decompression)

@@ -396,6 +396,33 @@ __global__ void __launch_bounds__(WAVE) k_hash_clear(const uint4* __restrict__ M
     g2_jac q0 = soa_ld_g2(M, mstride, 2 * (size_t)i), q1 = soa_ld_g2(M, mstride, 2 * (size_t)i + 1);
     soa_st_g2(H, stride, i, clear_cofactor_g2_with(jac_add(q0, q1), park, mul_inplace{}));
 }
+#if defined(BLS_CLEAR_TWO_WAVE)
+// EXPERIMENT (round 6, review item 4; builds made with -DBLS_CLEAR_TWO_WAVE only): the same generated kernel body for 256 registers and two
+// waves per SIMD (tools/gen_clear_asm.py --two-wave): no AGPRs, no LDS - what the one-wave form parks there travels through a wave-private block of
+// global memory (252 rows of 256 bytes) and a third scratch column; the doubling loop touches neither.  A flagged lane leaves Z = 0 for
+// k_clear_fix (the complete formulas need the whole register file).  `scratch` (the context's line store): three per-lane columns, rows 0 .. 71;
+// `wave_blocks`: k_pkmul's table buffer, idle while the hashing runs (the line store's columns >= n belong to the extra pairs' lines, which a
+// latency-mode call writes on the fork stream at the same time).
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "../build/clear2_asm.inc"
+#endif
+__global__ void __launch_bounds__(WAVE, 2) k_hash_clear2(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride, uint4* __restrict__ scratch,
+                                                          uint4* __restrict__ wave_blocks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* wblock = wave_blocks + (size_t)blockIdx.x * (252 * 256 / 16);
+    uint32_t flag;
+    asm volatile(BLS_CLEAR2_ASM_BODY
+                 : "=v"(flag)
+                 : "s"(M), "s"((uint32_t)(mstride * 16)), "s"(H), "s"((uint32_t)(stride * 16)), "s"(scratch), "s"((uint32_t)(stride * 16)), "v"(i), "s"(0u), "s"(wblock)
+                 : BLS_CLEAR2_ASM_CLOBBERS);
+    if (flag) {                                   // mark for k_clear_fix: Z = 0
+        soa_st2(H, stride, 4, i, fp2_zero());
+    }
+#endif
+}
+#endif
 // test entry (mi355_bls_debug_g2_clear_cofactor): pairs of blst_p2 images -> the SoA layout k_hash_map leaves its mapped points in
 __global__ void __launch_bounds__(WAVE) k_debug_to_soa(const uint32_t* __restrict__ in, uint32_t npoints, uint4* __restrict__ M, size_t mstride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
