@@ -69,8 +69,9 @@ int mi355_bls_recommend_hw_queues(void);
 int mi355_bls_ctx_set_num_threads(mi355_bls_ctx* ctx, uint32_t num_threads);
 
 /* Latency mode (on = 1, the default) or throughput mode (on = 0) of a context.
- * Latency mode shortens ONE call at the price of some extra lane-work: batches of up to 8 192 sets (which do not fill the chip
- * with one lane per set) run their cofactor clearing and Miller lines with 8 lanes per set (4 096 sets: 15 -> 6.8 ms);
+ * Latency mode shortens ONE call at the price of some extra lane-work: batches of up to ~11 000 sets (which do not fill the chip
+ * with one lane per set) run their cofactor clearing and Miller lines on the lane-team engine, 16 lanes per set (4 096 sets:
+ * 15 ms in round 1, 5.35 in round 5, 3.9 ms now), with [r]PK and the signature side on two fork streams beside the hashing;
  * whole-chip batches run the signature side and the Miller lines of its extra pairs on a second stream beside the hashing, so
  * that no nearly empty round of waves follows a full one; the partial line products are folded on the lane-cooperative Fp12
  * engine, whose workgroups have three waves in this mode.
@@ -80,9 +81,9 @@ int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* ctx, int on);
 
 /* batchVerifyParallel / batchVerify raw-pointer overloads (bls_batch_verifier.nim:296-302,420-426):
  * sets = n x 320-byte SignatureSet records in HOST memory, rnd = secureRandomBytes. n == 0 -> 0.
- * WHEN TO CALL IT: one blocking call costs about 4.1 ms for any n up to ~1 000 (latency-bound chains: hash-to-G2, Miller walk, final
- * exponentiation), 5.4 ms at 4 096, 13.6 ms at 65 536 (11.3 ms per batch when three are kept in flight).  A CPU BLST verifies a small batch
- * faster than that: below about 9 sets per host core (~140 sets on 16 cores; bench.py's `crossover`, INTEGRATION.md "When to call the
+ * WHEN TO CALL IT: one blocking call costs about 3.2 ms for any n up to ~1 000 (latency-bound chains: hash-to-G2, Miller walk, final
+ * exponentiation), 3.9 ms at 4 096, 13 ms at 65 536 (11 ms per batch when three are kept in flight).  A CPU BLST verifies a small batch
+ * faster than that: below about 7 sets per host core (~105 sets on 16 cores; bench.py's `crossover`, INTEGRATION.md "When to call the
  * GPU") a host should keep its CPU path, as the Nim shim of INTEGRATION.md does (Mi355MinSets).  Many small batches at once:
  * mi355_bls_batch_verify_many. */
 int mi355_bls_batch_verify(mi355_bls_ctx* ctx, const void* sets, size_t n, const uint8_t rnd[32]);
@@ -382,7 +383,8 @@ int mi355_bls_last_timings(mi355_bls_ctx* ctx, float out[8]);
 int mi355_bls_last_kernel_timings(mi355_bls_ctx* ctx, float out[4]);
 
 /* TEST HOOK: out[i] = clear_cofactor(q0_i + q1_i) (RFC 9380 G.3, the last stage of hash-to-G2) for n <= max_sets pairs of blst_p2 images
- * (2 x 288 B per pair, host memory), computed by k_hash_clear itself - lets the tests put points through the kernel that no hash produces
+ * (2 x 288 B per pair, host memory), computed by the kernels the batch path would launch for this context (k_hash_clear on a throughput-mode context, the lane-team engine on a
+ * latency-mode one) - lets the tests put points through them that no hash produces
  * (the point at infinity, equal or opposite points: the cases its incomplete addition formulas flag and recompute). */
 int mi355_bls_debug_g2_clear_cofactor(mi355_bls_ctx* ctx, const uint8_t* in_pairs, size_t n, uint8_t* out_p2);
 
