@@ -534,7 +534,7 @@ __device__ __forceinline__ bool tvm_clear_cofactor(tvm_lds_char* team, uint32_t 
 // their independent products over roles 0..2.  Every group of 8 lanes does the same work.
 __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, xmd32_consts xc, uint4* __restrict__ H, size_t stride, size_t slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
+    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
     const uint32_t lane16 = threadIdx.x & 15u;                      // every team of 16 lanes does the same work
     tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
 #ifdef BLS_TAIL_CLOCK
@@ -560,9 +560,9 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
     g2_jac q = iso3_g2(qs);
     if (lane16 < 2) {                                               // q0 -> the engine's slots X, Y, Z; q1 -> BX, BY, BZ
         const uint32_t s0 = (TVM_CLEAR_X + 6 * lane16) * TVM_SLOT_BYTES;
-        tvm_st(team, s0, fp_reduce(q.x.c0)); tvm_st(team, s0 + 64, fp_reduce(q.x.c1));
-        tvm_st(team, s0 + 128, fp_reduce(q.y.c0)); tvm_st(team, s0 + 192, fp_reduce(q.y.c1));
-        tvm_st(team, s0 + 256, fp_reduce(q.z.c0)); tvm_st(team, s0 + 320, fp_reduce(q.z.c1));
+        tvm_st(team, s0, fp_reduce(q.x.c0)); tvm_st(team, s0 + TVM_SLOT_BYTES, fp_reduce(q.x.c1));
+        tvm_st(team, s0 + 2 * TVM_SLOT_BYTES, fp_reduce(q.y.c0)); tvm_st(team, s0 + 3 * TVM_SLOT_BYTES, fp_reduce(q.y.c1));
+        tvm_st(team, s0 + 4 * TVM_SLOT_BYTES, fp_reduce(q.z.c0)); tvm_st(team, s0 + 5 * TVM_SLOT_BYTES, fp_reduce(q.z.c1));
     }
 #ifdef BLS_TAIL_CLOCK
     ts[3] = __builtin_amdgcn_s_memtime();
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
 // batches that leave wave slots free at 16 lanes per message
 __device__ __forceinline__ void team_clear_body(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * 4];
+    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
     const uint32_t lane16 = threadIdx.x & 15u;
     tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
     uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 4);
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(WAVE) k_clear_fix(const uint4* __restrict__ M,
 __device__ __forceinline__ void team_lines_body(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
                                                 uint4* __restrict__ lines) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ bls_u32x4 lds[4 * TVM_LINES_SLOTS * 4];
+    __shared__ bls_u32x4 lds[4 * TVM_LINES_SLOTS * (TVM_SLOT_BYTES / 16)];
     const uint32_t lane16 = threadIdx.x & 15u;
     tvm_lds_char* team = tvm_team_base<TVM_LINES_SLOTS>(lds);
     uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 4);

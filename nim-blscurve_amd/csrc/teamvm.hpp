@@ -17,7 +17,7 @@
 namespace bls {
 
 constexpr uint32_t TVM_F_LINEAR = 1u << 16, TVM_F_GSTORE = 1u << 17, TVM_STEP_SHIFT = 20, TVM_NO_PLANE = 15;
-constexpr int TVM_TEAM = 16, TVM_SLOT_BYTES = 64;
+constexpr int TVM_TEAM = 16, TVM_SLOT_BYTES = 80;      // 64 bytes of limbs + 16 of padding (LDS banks: tools/teamvm.py SLOT_BYTES)
 
 BLS_HD int32_t tvm_sbyte(uint32_t w, int k) { return (int32_t)(w << (24 - 8 * k)) >> 24; }
 
@@ -105,15 +105,16 @@ __device__ __forceinline__ void tvm_run(tvm_lds_char* team, uint32_t lane16, con
         // both are on their way during the product and neither is waited for before the next round needs it
         const uint32_t enn = seq[i + 2];
         const uint4 dn = dtab[(en & 0xffffu) * TVM_TEAM];
+        // all three operands are requested at once (one LDS latency per round, not three): b is the zero slot in a linear round
         const fp a = tvm_ld(team, d.x & 0xffffu);
+        const fp b = tvm_ld(team, d.x >> 16);
+        const fp t = tvm_ld(team, d.y & 0xffffu);
         fp v;
         if (e & TVM_F_LINEAR) {
             v = a;
         } else {
-            const fp b = tvm_ld(team, d.x >> 16);
             v = fp_mul_core(a, b);
         }
-        const fp t = tvm_ld(team, d.y & 0xffffu);
         const fp v1 = tvm_quad<0xb1>(v), v2 = tvm_quad<0x4e>(v), v3 = tvm_quad<0x1b>(v);      // lanes l ^ 1, l ^ 2, l ^ 3 of the quad
         fp o = tvm_post(v, v1, v2, v3, t, tvm_sbyte(d.z, 0), tvm_sbyte(d.z, 1), tvm_sbyte(d.z, 2), tvm_sbyte(d.z, 3), tvm_sbyte(d.w, 0));
         tvm_st(team, d.y >> 16, o);

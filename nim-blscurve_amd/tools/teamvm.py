@@ -7,7 +7,7 @@ blst_abi.nim:383, :455).
 The engine, and why it looks like this.  Rounds 1-5 ran these chains as compiled "team" formulas: every lane held
 every intermediate of the formula in registers (700 spilled registers), picked its operands with 14-instruction selects and read the
 others' results with 14-shuffle gathers: ~5 300 cycles per round for a 1 840-cycle Fp product.  Here the team's values live in LDS as
-64-byte Fp SLOTS and the formulas are DATA: a program is a list of ROUNDS, a round gives each of the 16 lanes one descriptor
+Fp SLOTS (64 bytes of limbs at a stride of 80) and the formulas are DATA: a program is a list of ROUNDS, a round gives each of the 16 lanes one descriptor
 
     v    = S[a] * S[b]                      one Montgomery product (392 multiply-adds), operands read from the team's slots by address
     out  = reduce(c0 v + c1 v^1 + c2 v^2 + c3 v^3 + ct S[t])      v^k: the product of lane (l xor k) of the same QUAD (three DPP moves)
@@ -32,7 +32,8 @@ import sys
 from asmlib import F2, P, R, RINV, X_ABS, mmul
 
 TEAM = 16
-SLOT_BYTES = 64
+SLOT_BYTES = 80                # 64 bytes of limbs + 16 of padding: slot s starts at bank 20 s mod 32, so eight lanes that read eight different
+                               # slots with ds_read_b128 hit eight different bank groups (at a stride of 64 bytes only two: 61 % of the LDS cycles were conflicts)
 # sequence entry: round index | flags
 F_LINEAR = 1 << 16           # no product: v = S[a]
 F_GSTORE = 1 << 17           # lanes with a line plane also write `out` to the line store; bits 20..27: the step

@@ -26,11 +26,11 @@ def test_programs_match_bigint_formulas():
     slots, distinct, nseq = map(int, m.groups())
     # two chains of 63 doublings (3 rounds) + 5 additions (5 rounds), 8 more additions, 9 preparations (2 rounds), one doubling, three psi, copies
     assert nseq <= 490 and distinct <= 40
-    assert 4 * slots * 64 <= 20 * 1024            # four teams of a wave: eight waves per CU fit the 160 KB of LDS
+    assert 4 * slots * 80 <= 25 * 1024            # four teams of a wave at the 80-byte slot stride: six waves per CU fit the 160 KB of LDS
     m = re.search(r"teamvm lines: (\d+) slots, (\d+) distinct rounds, (\d+) in sequence \((\d+) linear\)", r.stdout)
     slots, distinct, nseq, nlin = map(int, m.groups())
     assert nseq == 2 + 63 * 4 + 5 * 5 and nlin == 63
-    assert 4 * slots * 64 <= 22 * 1024
+    assert 4 * slots * 80 <= 27 * 1024
 
 
 def test_tables_are_well_formed():
@@ -46,8 +46,8 @@ def test_tables_are_well_formed():
         for i in range(0, len(words), 4):
             w0, w1, w2, w3 = words[i:i + 4]
             for off in (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16):
-                assert off % 64 == 0 and off // 64 < obj.s.n               # every operand / destination is a slot of the team's region
-            assert (w1 >> 16) // 64 != prog.zero                            # nothing ever writes the zero slot
+                assert off % tv.SLOT_BYTES == 0 and off // tv.SLOT_BYTES < obj.s.n               # every operand / destination is a slot of the team's region
+            assert (w1 >> 16) // tv.SLOT_BYTES != prog.zero                            # nothing ever writes the zero slot
             cs = [(w2 >> (8 * k)) & 0xff for k in range(4)] + [w3 & 0xff]
             assert sum(c - 256 if c & 0x80 else c if c < 0x80 else 0 for c in cs) is not None
             assert sum(abs(c - 256 if c & 0x80 else c) for c in cs) <= 64   # the reduction's quotient estimate
