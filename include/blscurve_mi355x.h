@@ -388,6 +388,10 @@ int mi355_bls_last_kernel_timings(mi355_bls_ctx* ctx, float out[4]);
  * (the point at infinity, equal or opposite points: the cases its incomplete addition formulas flag and recompute). */
 int mi355_bls_debug_g2_clear_cofactor(mi355_bls_ctx* ctx, const uint8_t* in_pairs, size_t n, uint8_t* out_p2);
 
+/* TEST HOOK: out_p2 = hash_to_G2(msg, dst) (blst_p2 image, Jacobian) computed by the one-message kernel of fastAggregateVerify / verify under ANY
+ * domain separation tag (1 .. 64 bytes): holds the device against published hash-to-curve vectors (RFC 9380 J.10.1), whose DST is not the scheme's. */
+int mi355_bls_debug_hash_to_g2(mi355_bls_ctx* ctx, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t out_p2[288]);
+
 /* Test hooks (no reference counterpart).  debug_fail_next_enqueue: the next batch / shard enqueue on this context fails with
  * MI355_BLS_ERR_HIP before touching the device (exercises the multi-device driver's clean-up path).  debug_multi_enqueue_us:
  * host time in microseconds, counted from the start of the last mi355_bls_batch_verify_multi* call of this thread, at which each

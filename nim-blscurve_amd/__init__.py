@@ -129,6 +129,7 @@ def lib():
         L.mi355_bls_debug_batches_in_flight.argtypes = []
         L.mi355_bls_last_fold_form.argtypes = [vp]
         L.mi355_bls_debug_g2_clear_cofactor.argtypes = [vp, cp, sz, cp]
+        L.mi355_bls_debug_hash_to_g2.argtypes = [vp, cp, sz, cp, sz, cp]
         L.mi355_bls_debug_multi_enqueue_us.argtypes = [ctypes.POINTER(ctypes.c_float), sz]
         L.mi355_bls_debug_multi_enqueue_us.restype = sz
         L.mi355_bls_fetch_stage.argtypes = [vp, i32, vp, sz]

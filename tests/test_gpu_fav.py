@@ -100,3 +100,27 @@ def test_one_message_hash_of_a_32_byte_message(m, cache):
         assert m.fastAggregateVerify(cache, pks, msg, sig) is True, len(msg)
         assert m.fastAggregateVerify(cache, pks, msg, bad) is False, len(msg)
     assert m.fastAggregateVerify(cache, pks, root[:31] + bytes([root[31] ^ 1]), co.g2_mul(co.hash_to_g2(root, o.DST_SIG), sum(sks) % o.R)) is False
+
+
+def test_hash_one_against_rfc9380_and_oracle(m):
+    """k_hash_one (two SSWU maps side by side, addition and cofactor clearing on the lane-team engine) through mi355_bls_debug_hash_to_g2: the RFC 9380
+    J.10.1 vector of the empty message (tests/test_oracle_kats.py says where it comes from) under the RFC's own DST, and messages of several lengths under
+    the scheme's DSTs against the oracle (32 bytes: the prepared-constants path; other lengths: the byte-wise absorber)."""
+    import ctypes
+    from util import g2_jac_to_affine
+    cache = m.BatchedBLSVerifierCache.init(max_sets=64)
+    out = ctypes.create_string_buffer(288)
+
+    def h(msg, dst):
+        assert m._check(m.lib().mi355_bls_debug_hash_to_g2(cache._h, msg, len(msg), dst, len(dst), out)) == 0
+        return g2_jac_to_affine(out.raw)
+
+    rfc = b"QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_"
+    assert h(b"", rfc) == ((int("0141ebfbdca40eb85b87142e130ab689c673cf60f1a3e98d69335266f30d9b8d4ac44c1038e9dcdd5393faf5c41fb78a", 16),
+                            int("05cb8437535e20ecffaef7752baddf98034139c38452458baeefab379ba13dff5bf5dd71b72418717047f5b0f37da03d", 16)),
+                           (int("0503921d7f6a12805e72940b963c0cf3471c7b2a524950ca195d11062ee75ec076daf2d4bc358c4b190c0c98064fdd92", 16),
+                            int("12424ac32561493f3fe3c260708a12b7c620e7be00099a974e259ddc7d1f6395c3c811cdd19f1e8dbf3e9ecfdcbab8d6", 16)))
+    pop = b"BLS_POP_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"
+    for msg, dst in ((b"abc", rfc), (bytes(range(32)), o.DST_SIG), (bytes(range(48)), pop), (b"x" * 200, o.DST_SIG), (bytes(32), pop)):
+        assert h(msg, dst) == o.hash_to_g2(msg, dst)
+    cache.close()

@@ -71,6 +71,17 @@ def test_hash_to_g2_stages(emu):
         assert o.g2_compress(ha).hex() == v["h_compressed"]
 
 
+def test_rfc9380_vector_through_the_device_arithmetic(emu):
+    """the RFC 9380 J.10.1 vector of the empty message (tests/test_oracle_kats.py says where it comes from) through the product's own hash_to_g2
+    (the code the kernels run, here on the CPU under the bounds tracker): affine output byte for byte"""
+    dst = b"QUUX-V01-CS02-with-BLS12381G2_XMD:SHA-256_SSWU_RO_"
+    h = g2_jac_to_affine(call(emu, "emu_hash_to_g2", b"", 0, dst, len(dst), outlen=288))
+    assert h == ((int("0141ebfbdca40eb85b87142e130ab689c673cf60f1a3e98d69335266f30d9b8d4ac44c1038e9dcdd5393faf5c41fb78a", 16),
+                  int("05cb8437535e20ecffaef7752baddf98034139c38452458baeefab379ba13dff5bf5dd71b72418717047f5b0f37da03d", 16)),
+                 (int("0503921d7f6a12805e72940b963c0cf3471c7b2a524950ca195d11062ee75ec076daf2d4bc358c4b190c0c98064fdd92", 16),
+                  int("12424ac32561493f3fe3c260708a12b7c620e7be00099a974e259ddc7d1f6395c3c811cdd19f1e8dbf3e9ecfdcbab8d6", 16)))
+
+
 def test_hash_to_field_fast_path_for_32_byte_messages(emu):
     """k_hash_map's specialised expand_message_xmd (message-independent words precomputed per DST) against the
     generic byte-wise one and the oracle, for several DST lengths incl. the edges of its range."""
