@@ -316,11 +316,7 @@ __global__ void __launch_bounds__(WAVE) k_blind_many(const uint8_t* __restrict__
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-#ifndef BLS_HASHMAP_WPS
-#define BLS_HASHMAP_WPS 2
-#endif
-__global__ void __launch_bounds__(WAVE, BLS_HASHMAP_WPS) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
-                                                         size_t mstride) {
+__device__ __forceinline__ void hash_map_body(const uint8_t* __restrict__ sets, uint32_t n, const dst_t& dst, const xmd32_consts& xc, uint4* __restrict__ M, size_t mstride) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
     if (i >= n) return;
     const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
@@ -344,6 +340,17 @@ __global__ void __launch_bounds__(WAVE, BLS_HASHMAP_WPS) k_hash_map(const uint8_
     }
     fp2 u = fp2_select((t & 1) != 0, u1, u0);
     soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
+}
+__global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
+                                                         size_t mstride) {
+    hash_map_body(sets, n, dst, xc, M, mstride);
+}
+// The same kernel for grids of at most one wave per SIMD (latency mode, up to 32 768 messages): the whole register file (nothing spills around the
+// square-root chains) and one wave per SIMD guaranteed - the dispatcher packs the 256-register form two per SIMD before every SIMD has a wave, and a
+// wave that shares its SIMD takes 1.4 x as long.
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_hash_map_spread(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M, size_t mstride) {
+    hash_map_body(sets, n, dst, xc, M, mstride);
 }
 // base point of the doubling chains parked in three LDS slots (21 KB of the 40 KB a wave may use)
 #if defined(__HIP_DEVICE_COMPILE__)
