@@ -984,6 +984,8 @@ def aux_rows(m, cache, dev):
     NF = 16
     c4 = [m.BatchedBLSVerifierCache.init(max_sets=n4, device=dev.index or 0) for _ in range(NF)]
     s4 = [torch.cuda.Stream(device=dev) for _ in range(NF)]
+    for c in c4[1:]:
+        c.set_cooperative(False)                   # many batches in flight: one lane per set is the efficient form (and such a context creates no fork streams)
     for c, st in zip(c4, s4):
         assert c.verify_device(d4.data_ptr(), n4, rnd, st.cuda_stream)
     # one blocking caller: on the default stream, as a plain blocking call from C or Nim is.  (On one of the sixteen torch streams created above the
@@ -996,8 +998,7 @@ def aux_rows(m, cache, dev):
     for _ in range(5):
         assert c4[0].verify_device(d4.data_ptr(), n4, rnd, 0)
     one4 = (time.perf_counter() - t0) / 5
-    for c in c4:
-        c.set_cooperative(False)                   # many batches in flight: one lane per set is the efficient form
+    c4[0].set_cooperative(False)
     row = {"ms_per_blocking_call": one4 * 1e3, "verifications_per_s_one_caller": n4 / one4}
     for nf in (8, NF):                             # independent callers, one context + stream each
         reps = 9 * nf
