@@ -1014,6 +1014,10 @@ def aux_rows(m, cache, dev):
         for i in range(nf):
             assert c4[(reps + i) % nf].wait()
         row["verifications_per_s_%d_in_flight" % nf] = n4 / ((time.perf_counter() - t0) / reps)
+    row["in_flight_note"] = ("one host thread submits and waits round robin, i.e. in lockstep with the slowest caller; HIP attaches a stream to the least-used of the "
+                             "GPU_MAX_HW_QUEUES hardware queues at its first use and callers that share a queue run in turn, so the same code reports ~2.6 M/s when the "
+                             "callers' streams fall two per queue and ~1.9 M/s when some queue holds three - which streams the PROCESS used before decides "
+                             "(profiles/r06_ab/fork_streams.txt, tests/gpu_probe_hq.py: 2.6 M/s in a fresh process); mi355_bls_batch_verify_many is the entry point for many small batches")
     out["batchVerify_4096"] = row
     for c in c4:
         c.close()
