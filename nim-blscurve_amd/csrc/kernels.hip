@@ -34,6 +34,7 @@
 #include "pairing.hpp"
 #include "c12.hpp"
 #include "teamvm.hpp"
+#include "rowfp.hpp"
 
 using namespace bls;
 
@@ -1742,6 +1743,57 @@ __global__ void __launch_bounds__(WAVE) k_pip_winsum(const uint32_t* __restrict_
 #pragma clang loop unroll(disable)
     for (uint32_t i = 0; i < sh; i++) acc = dbl_coop(acc);
     if (threadIdx.x == 0) st_jac_int(winout + (size_t)w * (3 * fld<F>::W), acc);
+}
+// G1, round 6: the window parts -> the windows' values -> ONE Horner walk over the windows [w0, w1), all of it on the limb-parallel row arithmetic
+// (rowfp.hpp: a dependent doubling in ~1.4 us where the DPP quad team above takes 4.2).  Wave v of the block sums the nsplit parts of windows v, v + 16, ...;
+// wave 0 then walks from window w1 - 1 down: acc = 2^(width) acc + R_w.  acc_in (48 words: X, Y, Z as sixteen limbs each) continues the walk of the window
+// group above; the group that ends at window 0 writes the blst image of the result, any other group its accumulator.
+__global__ void __launch_bounds__(1024) k_pip_rowtail(const uint32_t* __restrict__ part, uint32_t nsplit, pip_win W, uint32_t w0, uint32_t w1, const uint32_t* __restrict__ acc_in,
+                                                      uint32_t* __restrict__ acc_out, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sums[64 * 48];
+    const row_ctx C = row_ctx_make();
+    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, l16 = threadIdx.x & 15u;
+    const bool row0 = (threadIdx.x & 63u) < 16u;
+#pragma clang loop unroll(disable)
+    for (uint32_t w = w0 + wave; w < w1; w += nwaves) {
+        const uint32_t* base = part + (size_t)w * nsplit * (3 * FPW);
+        row_g1 acc{row_load(base), row_load(base + FPW), row_load(base + 2 * FPW)};
+#pragma clang loop unroll(disable)
+        for (uint32_t j = 1; j < nsplit; j++) {
+            const uint32_t* q = base + (size_t)j * (3 * FPW);
+            acc = row_add(C, acc, row_g1{row_load(q), row_load(q + FPW), row_load(q + 2 * FPW)});
+        }
+        if (row0) {
+            uint32_t* d = sums + (w - w0) * 48;
+            d[l16] = (uint32_t)acc.x; d[16 + l16] = (uint32_t)acc.y; d[32 + l16] = (uint32_t)acc.z;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    row_g1 acc;
+    uint32_t w = w1;
+    if (acc_in) {
+        acc = row_g1{(rw)acc_in[l16], (rw)acc_in[16 + l16], (rw)acc_in[32 + l16]};
+    } else {
+        w--;
+        const uint32_t* d = sums + (w - w0) * 48;
+        acc = row_g1{(rw)d[l16], (rw)d[16 + l16], (rw)d[32 + l16]};
+    }
+#pragma clang loop unroll(disable)
+    while (w > w0) {
+        w--;
+        const uint32_t sh = pip_off(W, w + 1) - pip_off(W, w);
+#pragma clang loop unroll(disable)
+        for (uint32_t i = 0; i < sh; i++) acc = row_dbl(C, acc);
+        const uint32_t* d = sums + (w - w0) * 48;
+        acc = row_add(C, acc, row_g1{(rw)d[l16], (rw)d[16 + l16], (rw)d[32 + l16]});
+    }
+    if (w0 == 0) {
+        const g1_jac r{fp_reduce(row_to_fp(acc.x)), fp_reduce(row_to_fp(acc.y)), fp_reduce(row_to_fp(acc.z))};
+        if (threadIdx.x == 0) st_jac_blst(out, r);
+    } else if (row0) {
+        acc_out[l16] = (uint32_t)acc.x; acc_out[16 + l16] = (uint32_t)acc.y; acc_out[32 + l16] = (uint32_t)acc.z;
+    }
 }
 // one wave: sum of the window values -> blst image (Jacobian)
 template <class F>

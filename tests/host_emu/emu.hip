@@ -8,10 +8,39 @@
 #include "deser.hpp"
 #include "c12.hpp"
 #include "teamvm.hpp"
+#define BLS_ROW_EMU 1                    // rowfp.hpp on 64 emulated lanes
+#include "rowfp.hpp"
 using namespace bls;
+static rw emu_row_of4(const uint8_t* p192) { return row_pick(row_from_fp(fp_load_le(p192)), row_from_fp(fp_load_le(p192 + 48)), row_from_fp(fp_load_le(p192 + 96)), row_from_fp(fp_load_le(p192 + 144))); }
+static void emu_row_to4(uint8_t* r192, const rw& x) {
+    fp_store_le(r192, fp_reduce(row_to_fp(row_from<0>(x)))); fp_store_le(r192 + 48, fp_reduce(row_to_fp(row_from<1>(x))));
+    fp_store_le(r192 + 96, fp_reduce(row_to_fp(row_from<2>(x)))); fp_store_le(r192 + 144, fp_reduce(row_to_fp(row_from<3>(x))));
+}
+static row_g1 emu_row_g1(const uint8_t* p144) { g1_jac p = g1_jac_load(p144); return row_g1{row_from_fp(p.x), row_from_fp(p.y), row_from_fp(p.z)}; }
+static void emu_row_g1_out(uint8_t* o144, const row_g1& r) { g1_jac_store(o144, g1_jac{fp_reduce(row_to_fp(r.x)), fp_reduce(row_to_fp(r.y)), fp_reduce(row_to_fp(r.z))}); }
 #define TVM_TABLE static
 #include "_build/teamvm_tables.inc"      // written by build.sh (nim-blscurve_amd/tools/teamvm.py): the tables the library embeds
 extern "C" {
+// The limb-parallel row arithmetic of the MSM's tail (csrc/rowfp.hpp) on 64 emulated lanes, every bound asserted.
+// four products at once, one per row
+void emu_row_mul(const uint8_t* a192, const uint8_t* b192, uint8_t* r192, int a_twice) {
+    const row_ctx C = row_ctx_make();
+    rw a = emu_row_of4(a192), b = emu_row_of4(b192);
+    if (a_twice) a = a + a;                      // the widest operand the formulas pass in: a doubled product
+    emu_row_to4(r192, row_mul(C, a, b));
+}
+void emu_row_dbl(const uint8_t* p144, uint8_t* o144, int times) {
+    const row_ctx C = row_ctx_make();
+    row_g1 p = emu_row_g1(p144);
+    for (int i = 0; i < times; i++) p = row_dbl(C, p);
+    emu_row_g1_out(o144, p);
+}
+void emu_row_add(const uint8_t* p144, const uint8_t* q144, uint8_t* o144, int dbl_first) {
+    const row_ctx C = row_ctx_make();
+    row_g1 p = emu_row_g1(p144), q = emu_row_g1(q144);
+    for (int i = 0; i < dbl_first; i++) p = row_dbl(C, p);         // operands as a doubling leaves them (the Horner walk's)
+    emu_row_g1_out(o144, row_add(C, p, q));
+}
 // The lane-team engine (csrc/teamvm.hpp) on sixteen emulated lanes, under the bounds tracker: the programs the library embeds, round by round.
 // q0 | q1 (2 x 288 B, Jacobian) -> clear_cofactor(q0 + q1) as the engine leaves it (288 B)
 void emu_tvm_clear(const uint8_t* q576, uint8_t* out288) {
