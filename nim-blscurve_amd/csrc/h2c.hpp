@@ -146,10 +146,15 @@ BLS_HD void hash_to_field_fp2x2_msg32(fp2& u0, fp2& u1, const uint32_t (&msg_be)
 
 // (is_square(N/D), y) with y = sqrt(N/D) if square, else sqrt(Z * N/D); Z = -(2+u), norm(Z) = 5.
 // Two Fp exponentiations; the first also yields 1/norm(D).
-BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
+// (`pw`: the exponentiation a^((p-3)/4) - fp_recip_sqrt_pow in every lane, or k_hash_one's row form, which computes the wave's two chains along DPP rows)
+struct pow_in_lane {
+    BLS_HD fp operator()(const fp& a) const { return fp_recip_sqrt_pow(a); }
+};
+template <class Pow>
+BLS_MID bool sqrt_ratio_fp2_with(fp2& y, const fp2& N, const fp2& D, const Pow& pw) {
     fp nN = fp2_norm(N), nD = fp2_norm(D);
     fp M = fp_mul(nN, nD);
-    fp t = fp_recip_sqrt_pow(M);
+    fp t = pw(M);
     fp s = fp_mul(M, t);                         // s^2 = M (QR) or -M
     bool is_sq = fp_eq(fp_sqr(s), M);
     fp t2 = fp_sqr(t);                           // M * t^2 = +-1
@@ -164,7 +169,7 @@ BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
     fp half = fp_from_const(k::HALF);
     fp d = fp_mul(fp_add(g.c0, n), half);
     d = fp_select(fp_is_zero(d), fp_reduce(g.c0), d);
-    fp t3 = fp_recip_sqrt_pow(d);
+    fp t3 = pw(d);
     fp x0 = fp_mul(d, t3);
     bool qr = fp_eq(fp_sqr(x0), d);
     fp bh = fp_mul(fp_mul(g.c1, half), t3);
@@ -172,9 +177,11 @@ BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) {
     y.c1 = fp_select(qr, bh, fp_neg(x0));
     return is_sq;
 }
+BLS_MID bool sqrt_ratio_fp2(fp2& y, const fp2& N, const fp2& D) { return sqrt_ratio_fp2_with(y, N, D, pow_in_lane{}); }
 
 // Simplified SWU onto E2': y^2 = x^3 + 240u x + 1012(1+u)  (RFC 9380 appendix F.2), Jacobian output.
-BLS_MID g2_jac sswu_g2(const fp2& u) {
+template <class Pow>
+BLS_MID g2_jac sswu_g2_with(const fp2& u, const Pow& pw) {
     const fp2 A = fp2_from_const(k::SSWU_A), B = fp2_from_const(k::SSWU_B), Z = fp2_from_const(k::SSWU_Z);
     fp2 tv1 = fp2_mul(Z, fp2_sqr(u));
     fp2 tv2 = fp2_add(fp2_sqr(tv1), tv1);
@@ -184,7 +191,7 @@ BLS_MID g2_jac sswu_g2(const fp2& u) {
     fp2 D = fp2_mul(xd2, xd);
     fp2 N = fp2_add(fp2_mul(fp2_add(fp2_sqr(xn), fp2_mul(A, xd2)), xn), fp2_mul(B, D));
     fp2 y1;
-    bool is_sq = sqrt_ratio_fp2(y1, N, D);
+    bool is_sq = sqrt_ratio_fp2_with(y1, N, D, pw);
     fp2 x2n = fp2_mul(tv1, xn);
     fp2 y2 = fp2_mul(fp2_mul(tv1, u), y1);
     fp2 x = fp2_select(is_sq, xn, x2n);
@@ -193,6 +200,7 @@ BLS_MID g2_jac sswu_g2(const fp2& u) {
     y = fp2_select(same, y, fp2_neg(y));
     return g2_jac{fp2_mul(x, xd), fp2_mul(y, D), xd};
 }
+BLS_MID g2_jac sswu_g2(const fp2& u) { return sswu_g2_with(u, pow_in_lane{}); }
 
 // 3-isogeny E2' -> E2 on Jacobian coordinates: (XN(X,Z^2), Y*YN(X,Z^2), Z*(X - xK Z^2))
 BLS_MID g2_jac iso3_g2(const g2_jac& p) {

@@ -317,9 +317,11 @@ __global__ void __launch_bounds__(WAVE) k_blind_many(const uint8_t* __restrict__
 // Fp exponentiations with a small live set), compiled for 256 registers so two waves share a SIMD and fill
 // each other's issue gaps; k_hash_clear: one lane per message adds the two points and clears the cofactor
 // (G2 arithmetic: needs the full register file).
-__device__ __forceinline__ void hash_map_body(const uint8_t* __restrict__ sets, uint32_t n, const dst_t& dst, const xmd32_consts& xc, uint4* __restrict__ M, size_t mstride) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
-    if (i >= n) return;
+// t: the (message, u) pair this lane maps; store: whether it writes the result (the row form below computes every pair in sixteen lanes)
+template <class Pow>
+__device__ __forceinline__ void hash_map_body_with(const uint8_t* __restrict__ sets, uint32_t t, bool store, const dst_t& dst, const xmd32_consts& xc, uint4* __restrict__ M,
+                                                   size_t mstride, const Pow& pw) {
+    const uint32_t i = t >> 1;
     const uint32_t* mw = reinterpret_cast<const uint32_t*>(sets + (size_t)i * 320 + 96);
     fp2 u0, u1;
     if (xc.valid) {                                   // wave-uniform: constants of this DST prepared on the host
@@ -340,7 +342,13 @@ __device__ __forceinline__ void hash_map_body(const uint8_t* __restrict__ sets, 
         hash_to_field_fp2x2(u0, u1, msg, 32, dst.b, dst.len);
     }
     fp2 u = fp2_select((t & 1) != 0, u1, u0);
-    soa_st_g2(M, mstride, t, iso3_g2(sswu_g2(u)));
+    const g2_jac q = iso3_g2(sswu_g2_with(u, pw));
+    if (store) soa_st_g2(M, mstride, t, q);
+}
+__device__ __forceinline__ void hash_map_body(const uint8_t* __restrict__ sets, uint32_t n, const dst_t& dst, const xmd32_consts& xc, uint4* __restrict__ M, size_t mstride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((t >> 1) >= n) return;
+    hash_map_body_with(sets, t, true, dst, xc, M, mstride, pow_in_lane{});
 }
 __global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M,
                                                          size_t mstride) {
@@ -352,6 +360,37 @@ __global__ void __launch_bounds__(WAVE, 2) k_hash_map(const uint8_t* __restrict_
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_hash_map_spread(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M, size_t mstride) {
     hash_map_body(sets, n, dst, xc, M, mstride);
+}
+// Small batches (at most one wave per SIMD at FOUR pairs per wave): a (message, u) pair per DPP row - the sixteen lanes of a row run the same hashing and
+// map arithmetic, and the two square-root exponentiations, 924 dependent products that are most of this kernel's time, run ALONG the row (rowfp.hpp:
+// ~0.44 us per product where a lane takes 0.7 - 0.9).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int I>
+__device__ __forceinline__ void row_spread_limbs(rw r, fp& out) {            // limb I of the row's value into every lane of the row
+    out.l[I] = (uint32_t)row_bcast<I>(r);
+    if constexpr (I + 1 < FP_N) row_spread_limbs<I + 1>(r, out);
+}
+struct pow_per_row {
+    const row_ctx& C;
+    uint32_t* tab;                    // LDS: 16 entries x 64 lanes, this lane's column
+    __device__ __forceinline__ fp operator()(const fp& a) const {          // a: the same in the sixteen lanes of a row
+        row_tab_lds T{tab, (uint32_t)WAVE};
+        const rw r = row_pow_sched(C, row_from_fp(a), k::SW_PM3D4, k::SW_PM3D4_LEN, T);
+        fp out;
+        row_spread_limbs<0>(r, out);
+        return fp_reduce(out);
+    }
+};
+#endif
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_hash_map_rows(const uint8_t* __restrict__ sets, uint32_t n, dst_t dst, xmd32_consts xc, uint4* __restrict__ M, size_t mstride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t powtab[16 * WAVE];
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool live = t < 2 * n;
+    const row_ctx RC = row_ctx_make();
+    hash_map_body_with(sets, live ? t : 0u, live && (threadIdx.x & 15u) == 0, dst, xc, M, mstride, pow_per_row{RC, powtab + threadIdx.x});
+#endif
 }
 // base point of the doubling chains parked in three LDS slots (21 KB of the 40 KB a wave may use)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -537,12 +576,37 @@ __device__ __forceinline__ bool tvm_clear_cofactor(tvm_lds_char* team, uint32_t 
     return !(tvm_slot_is_zero(team, TVM_CLEAR_Z) & tvm_slot_is_zero(team, TVM_CLEAR_Z + 1));
 }
 #endif
+// a^((p-3)/4) for the operands of lanes 0 and 1 of a wave, each along the rows of its parity; every lane gets the result of lane (lane & 15) == 1 ? 1 : 0
+struct pow_two_rows {
+    const row_ctx& C;
+    uint32_t* tab;                    // LDS: 16 entries x 64 lanes, this lane's column
+    __device__ __forceinline__ fp operator()(const fp& a) const {
+        const uint32_t l16 = threadIdx.x & 15u;
+        const bool odd = (threadIdx.x & 16u) != 0;
+        rw x = 0;
+#pragma unroll
+        for (int i = 0; i < FP_N; i++) {
+            const uint32_t v0 = __builtin_amdgcn_readlane(a.l[i], 0), v1 = __builtin_amdgcn_readlane(a.l[i], 1);
+            x = l16 == (uint32_t)i ? (rw)(odd ? v1 : v0) : x;
+        }
+        row_tab_lds T{tab, (uint32_t)WAVE};
+        const rw r = row_pow_sched(C, x, k::SW_PM3D4, k::SW_PM3D4_LEN, T);
+        fp out;
+#pragma unroll
+        for (int i = 0; i < FP_N; i++) {
+            const uint32_t v0 = __builtin_amdgcn_readlane(r, i), v1 = __builtin_amdgcn_readlane(r, 16 + i);
+            out.l[i] = l16 == 1u ? v1 : v0;
+        }
+        return fp_reduce(out);
+    }
+};
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
 // their independent products over roles 0..2.  Every group of 8 lanes does the same work.
 __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, xmd32_consts xc, uint4* __restrict__ H, size_t stride, size_t slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
+    __shared__ uint32_t powtab[16 * WAVE];
     const uint32_t lane16 = threadIdx.x & 15u;                      // every team of 16 lanes does the same work
     tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
 #ifdef BLS_TAIL_CLOCK
@@ -561,7 +625,10 @@ __global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ m
 #ifdef BLS_TAIL_CLOCK
     ts[1] = __builtin_amdgcn_s_memtime();
 #endif
-    g2_jac qs = sswu_g2(fp2_select(lane16 == 1, u1, u0));           // the two maps side by side in lanes 0 and 1 of the team
+    // the two maps side by side in lanes 0 and 1 of the team; their square-root exponentiations (924 dependent products, most of this kernel's time) run as
+    // two chains along DPP rows (rowfp.hpp: ~0.44 us per product where a lane takes 0.7 - 0.9): rows 0 / 2 take lane 0's operand, rows 1 / 3 lane 1's
+    const row_ctx RC = row_ctx_make();
+    g2_jac qs = sswu_g2_with(fp2_select(lane16 == 1, u1, u0), pow_two_rows{RC, powtab + threadIdx.x});
 #ifdef BLS_TAIL_CLOCK
     ts[2] = __builtin_amdgcn_s_memtime();
 #endif

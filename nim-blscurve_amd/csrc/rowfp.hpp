@@ -219,4 +219,42 @@ ROW_FN row_g1 row_add(const row_ctx& C, const row_g1& p, const row_g1& q) {
     return r;
 }
 
+// a^e along a row for a fixed exponent given as fp_pow_sched's 5-bit sliding-window schedule (constants.hpp: pairs of (squarings, odd multiplier)).  The table of
+// odd powers is kept by `tab` (put / get by index: LDS on the device - one word per lane and entry - an array on the CPU).  In: limbs as row_mul takes them.
+template <class Tab>
+ROW_FN rw row_pow_sched(const row_ctx& C, const rw& a, const uint8_t (*sched)[2], int len, Tab& tab) {
+    tab.put(0, a);
+    const rw a2 = row_mul(C, a, a);
+    rw t = a;
+#pragma clang loop unroll(disable)
+    for (int i = 1; i < 16; i++) {
+        t = row_mul(C, t, a2);
+        tab.put(i, t);
+    }
+    rw r = tab.get(sched[0][1] >> 1);
+#pragma clang loop unroll(disable)
+    for (int j = 1; j < len; j++) {
+        const int nsq = sched[j][0];
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < nsq; i++) r = row_mul(C, r, r);
+        const uint32_t v = sched[j][1];
+        if (v) r = row_mul(C, r, tab.get(v >> 1));
+    }
+    return r;
+}
+#if defined(BLS_ROW_EMU)
+struct row_tab_array {
+    rw t[16];
+    void put(int i, const rw& v) { t[i] = v; }
+    rw get(int i) const { return t[i]; }
+};
+#else
+struct row_tab_lds {                   // 16 entries x the block's lanes, one word each
+    uint32_t* base;                    // LDS, this lane's column: entry i at base[i * stride]
+    uint32_t stride;
+    __device__ __forceinline__ void put(int i, rw v) { base[i * stride] = (uint32_t)v; }
+    __device__ __forceinline__ rw get(int i) const { return (rw)base[i * stride]; }
+};
+#endif
+
 }  // namespace bls

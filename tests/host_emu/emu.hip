@@ -29,6 +29,11 @@ void emu_row_mul(const uint8_t* a192, const uint8_t* b192, uint8_t* r192, int a_
     if (a_twice) a = a + a;                      // the widest operand the formulas pass in: a doubled product
     emu_row_to4(r192, row_mul(C, a, b));
 }
+void emu_row_pow(const uint8_t* a192, uint8_t* r192) {                // a^((p-3)/4) of four values, one per row (k_hash_one's square-root chains)
+    const row_ctx C = row_ctx_make();
+    row_tab_array T;
+    emu_row_to4(r192, row_pow_sched(C, emu_row_of4(a192), k::SW_PM3D4, k::SW_PM3D4_LEN, T));
+}
 void emu_row_dbl(const uint8_t* p144, uint8_t* o144, int times) {
     const row_ctx C = row_ctx_make();
     row_g1 p = emu_row_g1(p144);

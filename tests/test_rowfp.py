@@ -57,3 +57,13 @@ def test_row_addition_and_its_exceptional_cases(emu):
             out = buf(144)
             emu.emu_row_add(a, b, out, dbl_first)
             assert g1_jac_to_affine(out.raw) == want
+
+
+def test_row_exponentiation_of_the_square_root(emu):
+    """k_hash_one's two SSWU square-root chains run along rows: a^((p-3)/4) by the library's own sliding-window schedule"""
+    rng = random.Random(8)
+    for a in ([rng.randrange(1, o.P) for _ in range(4)], [1, o.P - 1, 2, (o.P - 1) // 2]):
+        out = buf(192)
+        emu.emu_row_pow(b"".join(map(_mont, a)), out)
+        got = [o.fp_from_mont_bytes(out.raw[48 * i:48 * i + 48]) for i in range(4)]
+        assert got == [pow(x, (o.P - 3) // 4, o.P) for x in a]
