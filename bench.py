@@ -884,7 +884,7 @@ def aux_rows(m, cache, dev):
     for _ in range(5):
         assert fav() == 1
     t = cache.timings()
-    out["fastAggregateVerify_32768"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3, "g1_sum_ms": t["blinding"],
+    out["fastAggregateVerify_32768"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3, "g1_sum_ms": t["blinding"], "stage_ms": {k: round(v, 4) for k, v in t.items()},
                                         "g1_sum_GBs_at_96B_per_key": 96.0 * n / (t["blinding"] * 1e-3) / 1e9,
                                         "note": "one pairing per call: latency-bound (wave-cooperative hash-to-G2, 2-pair Miller loop with 8 lanes per pair, final exponentiation)"}
     # config 1 shape on the device: ONE (pk, msg, sig) verification = fastAggregateVerify with one key (latency of the whole pipeline)

@@ -64,6 +64,22 @@ def test_msm_edges(m, cache):
     assert g1_jac_to_affine(m.p1s_mult_pippenger(cache, pts[:96] + neg, sc[:32] * 2, 255)) is None
 
 
+def test_msm_tail_meets_equal_and_opposite_operands(m, cache):
+    """The Horner walk of the row tail (k_pip_rowtail: acc = 2^c acc + R_w) with inputs that make its addition exceptional, whatever the window
+    width c the plan picks: [2^c] P + 2^c P has acc == R_0 (the doubling branch), [2^c] P - 2^c P has acc == -R_0 (infinity), and a scalar that is a
+    multiple of every candidate 2^c leaves R_0 at infinity."""
+    rng = random.Random(91)
+    P = o.g1_mul(o.G1_GEN, rng.randrange(1, o.R))
+    le = lambda k: k.to_bytes(32, "little")
+    for c in range(3, 18):
+        Q = o.g1_mul(P, 1 << c)
+        for pts, ks in (([P, Q], [1 << c, 1]), ([P, o.g1_neg(Q)], [1 << c, 1]), ([P, Q], [1 << c, 0]), ([P, Q, P], [1 << c, 1, (1 << c) + 1])):
+            raw = b"".join(o.g1_to_blst_affine(q) for q in pts)
+            for nbits in (c + 1, 64, 255):
+                got = g1_jac_to_affine(m.p1s_mult_pippenger(cache, raw, b"".join(map(le, ks)), nbits))
+                assert got == o.msm_g1(pts, ks, nbits), (c, ks, nbits)
+
+
 @pytest.mark.parametrize("n", [1000, 20000, 50000])
 def test_msm_vs_c_oracle(m, cache, n):
     """bench shape: P_i = [a_i]G with 96-bit a_i, 32 random scalar bytes, nbits = 255."""
