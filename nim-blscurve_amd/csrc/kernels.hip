@@ -35,6 +35,7 @@
 #include "c12.hpp"
 #include "teamvm.hpp"
 #include "rowfp.hpp"
+#include "rowvm.hpp"
 
 using namespace bls;
 
@@ -603,53 +604,49 @@ struct pow_two_rows {
 // ONE message of any length (fastAggregateVerify / coreVerify shape): latency is all that matters, so a wave works on
 // it cooperatively: the two SSWU maps run in roles 0 and 1, the doubling chains of the cofactor clearing spread
 // their independent products over roles 0..2.  Every group of 8 lanes does the same work.
-__global__ void __launch_bounds__(WAVE) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, xmd32_consts xc, uint4* __restrict__ H, size_t stride, size_t slot) {
+__global__ void __launch_bounds__(256) k_hash_one(const uint8_t* __restrict__ msg, uint32_t len, dst_t dst, xmd32_consts xc, uint4* __restrict__ H, size_t stride, size_t slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ bls_u32x4 lds[4 * TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
+    // 256 lanes: wave 0 hashes and maps (the two SSWU maps in lanes 0 and 1 of every team of 16, their square-root chains along DPP rows); then the
+    // cofactor clearing runs on the ROW executor (rowvm.hpp): the engine's 486 rounds with a row of 16 lanes per product, four waves for the one message
+    __shared__ bls_u32x4 lds[TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
     __shared__ uint32_t powtab[16 * WAVE];
-    const uint32_t lane16 = threadIdx.x & 15u;                      // every team of 16 lanes does the same work
-    tvm_lds_char* team = tvm_team_base<TVM_CLEAR_SLOTS>(lds);
-#ifdef BLS_TAIL_CLOCK
-    unsigned long long ts[5];
-    ts[0] = __builtin_amdgcn_s_memtime();
-#endif
-    fp2 u0, u1;
-    if (xc.valid && len == 32) {                      // the usual message (a 32-byte signing root): the batch path's 18 compressions with the DST's words prepared
-        uint32_t mbe[8];                              // on the host - the byte-wise absorber below costs 0.23 ms for such a message, this form 0.05
-#pragma unroll
-        for (int j = 0; j < 8; j++) mbe[j] = ((uint32_t)msg[4 * j] << 24) | ((uint32_t)msg[4 * j + 1] << 16) | ((uint32_t)msg[4 * j + 2] << 8) | (uint32_t)msg[4 * j + 3];
-        hash_to_field_fp2x2_msg32(u0, u1, mbe, xc);
-    } else {
-        hash_to_field_fp2x2(u0, u1, msg, len, dst.b, dst.len);
-    }
-#ifdef BLS_TAIL_CLOCK
-    ts[1] = __builtin_amdgcn_s_memtime();
-#endif
-    // the two maps side by side in lanes 0 and 1 of the team; their square-root exponentiations (924 dependent products, most of this kernel's time) run as
-    // two chains along DPP rows (rowfp.hpp: ~0.44 us per product where a lane takes 0.7 - 0.9): rows 0 / 2 take lane 0's operand, rows 1 / 3 lane 1's
+    tvm_lds_char* item = (tvm_lds_char*)(tvm_lds_u32x4*)lds;
     const row_ctx RC = row_ctx_make();
-    g2_jac qs = sswu_g2_with(fp2_select(lane16 == 1, u1, u0), pow_two_rows{RC, powtab + threadIdx.x});
-#ifdef BLS_TAIL_CLOCK
-    ts[2] = __builtin_amdgcn_s_memtime();
-#endif
-    g2_jac q = iso3_g2(qs);
-    if (lane16 < 2) {                                               // q0 -> the engine's slots X, Y, Z; q1 -> BX, BY, BZ
-        const uint32_t s0 = (TVM_CLEAR_X + 6 * lane16) * TVM_SLOT_BYTES;
-        tvm_st(team, s0, fp_reduce(q.x.c0)); tvm_st(team, s0 + TVM_SLOT_BYTES, fp_reduce(q.x.c1));
-        tvm_st(team, s0 + 2 * TVM_SLOT_BYTES, fp_reduce(q.y.c0)); tvm_st(team, s0 + 3 * TVM_SLOT_BYTES, fp_reduce(q.y.c1));
-        tvm_st(team, s0 + 4 * TVM_SLOT_BYTES, fp_reduce(q.z.c0)); tvm_st(team, s0 + 5 * TVM_SLOT_BYTES, fp_reduce(q.z.c1));
+    g2_jac q;
+    if (threadIdx.x < WAVE) {
+        const uint32_t lane16 = threadIdx.x & 15u;
+        fp2 u0, u1;
+        if (xc.valid && len == 32) {                      // the usual message (a 32-byte signing root): the batch path's 18 compressions with the DST's words prepared
+            uint32_t mbe[8];                              // on the host - the byte-wise absorber below costs 0.23 ms for such a message, this form 0.05
+#pragma unroll
+            for (int j = 0; j < 8; j++) mbe[j] = ((uint32_t)msg[4 * j] << 24) | ((uint32_t)msg[4 * j + 1] << 16) | ((uint32_t)msg[4 * j + 2] << 8) | (uint32_t)msg[4 * j + 3];
+            hash_to_field_fp2x2_msg32(u0, u1, mbe, xc);
+        } else {
+            hash_to_field_fp2x2(u0, u1, msg, len, dst.b, dst.len);
+        }
+        // rows 0 / 2 take lane 0's operand of an exponentiation, rows 1 / 3 lane 1's (pow_two_rows)
+        q = iso3_g2(sswu_g2_with(fp2_select(lane16 == 1, u1, u0), pow_two_rows{RC, powtab + threadIdx.x}));
+        if (threadIdx.x < 2) {                                          // q0 -> the engine's slots X, Y, Z; q1 -> BX, BY, BZ
+            const uint32_t s0 = (TVM_CLEAR_X + 6 * threadIdx.x) * TVM_SLOT_BYTES;
+            tvm_st(item, s0, fp_reduce(q.x.c0)); tvm_st(item, s0 + TVM_SLOT_BYTES, fp_reduce(q.x.c1));
+            tvm_st(item, s0 + 2 * TVM_SLOT_BYTES, fp_reduce(q.y.c0)); tvm_st(item, s0 + 3 * TVM_SLOT_BYTES, fp_reduce(q.y.c1));
+            tvm_st(item, s0 + 4 * TVM_SLOT_BYTES, fp_reduce(q.z.c0)); tvm_st(item, s0 + 5 * TVM_SLOT_BYTES, fp_reduce(q.z.c1));
+        } else if (threadIdx.x == 2) {
+            tvm_st(item, TVM_CLEAR_zero * TVM_SLOT_BYTES, fp_zero());
+        } else if (threadIdx.x >= 12 && threadIdx.x < 16) {
+            const fp2 cx = fp2_from_const(k::PSI_CX), cy = fp2_from_const(k::PSI_CY);
+            tvm_st(item, (TVM_CLEAR_CX + (threadIdx.x - 12)) * TVM_SLOT_BYTES,
+                   fp_reduce(fp_select(threadIdx.x < 14, fp_select(threadIdx.x == 12, cx.c0, cx.c1), fp_select(threadIdx.x == 14, cy.c0, cy.c1))));
+        }
     }
-#ifdef BLS_TAIL_CLOCK
-    ts[3] = __builtin_amdgcn_s_memtime();
-#endif
-    const bool ok = tvm_clear_cofactor(team, lane16);               // q0 + q1 and the cofactor clearing on the lane-team engine
-#ifdef BLS_TAIL_CLOCK
-    ts[4] = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) printf("k_hash_one ticks: hash_to_field %llu  sswu %llu  isogeny+store %llu  add+cofactor (team engine) %llu\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
-#endif
+    __syncthreads();
+    rvm_run<false>(RC, item, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, tvm_line_sink{});
+    if (threadIdx.x >= WAVE) return;
+    // Z = 0 mod p: an exceptional case of the incomplete additions on the way (or a true point at infinity) - the complete formulas on one lane
+    const bool ok = !(fp_is_zero(tvm_ld(item, TVM_CLEAR_Z * TVM_SLOT_BYTES)) & fp_is_zero(tvm_ld(item, (TVM_CLEAR_Z + 1) * TVM_SLOT_BYTES)));
     if (ok) {
-        if (threadIdx.x < 6 && blockIdx.x == 0) soa_st(H, stride, threadIdx.x, slot, tvm_ld(team, (TVM_CLEAR_X + threadIdx.x) * TVM_SLOT_BYTES));
-    } else {                                                        // wave-uniform (every team computed the same): the complete formulas on one lane
+        if (threadIdx.x < 6 && blockIdx.x == 0) soa_st(H, stride, threadIdx.x, slot, fp_reduce(tvm_ld(item, (TVM_CLEAR_X + threadIdx.x) * TVM_SLOT_BYTES)));
+    } else {
         const uint32_t gbase = threadIdx.x & ~15u;
         g2_jac q0{fp2_from_role(q.x, gbase, 0), fp2_from_role(q.y, gbase, 0), fp2_from_role(q.z, gbase, 0)};
         g2_jac q1{fp2_from_role(q.x, gbase, 1), fp2_from_role(q.y, gbase, 1), fp2_from_role(q.z, gbase, 1)};
@@ -673,6 +670,28 @@ __device__ __forceinline__ void team_clear_body(const uint4* __restrict__ M, siz
     // such messages by their Z and recomputes them with the complete formulas - in a kernel of its own, so that this one keeps the engine's
     // ~100 registers (the complete formulas need all 512) and several waves fit a SIMD
     if (live && lane16 < 6) soa_st(H, stride, lane16, i, tvm_ld(team, (TVM_CLEAR_X + lane16) * TVM_SLOT_BYTES));
+#endif
+}
+// Small batches (a few hundred messages at most): the engine's program on the ROW executor, a workgroup of four waves per message (rowvm.hpp)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_clear_rows(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 lds[TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
+    tvm_lds_char* item = (tvm_lds_char*)(tvm_lds_u32x4*)lds;
+    const row_ctx RC = row_ctx_make();
+    const uint32_t i = blockIdx.x, t = threadIdx.x;
+    if (t < 12) {
+        tvm_st(item, (TVM_CLEAR_X + t) * TVM_SLOT_BYTES, fp_reduce(soa_ld(M, mstride, t % 6, 2 * (size_t)i + t / 6)));
+    } else if (t < 16) {
+        const fp2 cx = fp2_from_const(k::PSI_CX), cy = fp2_from_const(k::PSI_CY);
+        tvm_st(item, (TVM_CLEAR_CX + (t - 12)) * TVM_SLOT_BYTES, fp_reduce(fp_select(t < 14, fp_select(t == 12, cx.c0, cx.c1), fp_select(t == 14, cy.c0, cy.c1))));
+    } else if (t == 16) {
+        tvm_st(item, TVM_CLEAR_zero * TVM_SLOT_BYTES, fp_zero());
+    }
+    __syncthreads();
+    rvm_run<false>(RC, item, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, tvm_line_sink{});
+    // partially reduced, canonical limbs on the way out: k_clear_fix (behind this kernel) finds the exceptional cases by Z = 0
+    if (t < 6) soa_st(H, stride, t, i, fp_reduce(tvm_ld(item, (TVM_CLEAR_X + t) * TVM_SLOT_BYTES)));
 #endif
 }
 // Two forms of each engine kernel, same code.  The plain one: ~100 registers, a SIMD takes several waves - for grids beyond one wave per SIMD.
@@ -720,6 +739,25 @@ __global__ void __launch_bounds__(WAVE) k_team_lines(const uint4* __restrict__ P
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_team_lines_spread(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride, uint4* __restrict__ lines) {
     team_lines_body(P, H, first, count, stride, lines);
+}
+// a workgroup of four waves per pair (rowvm.hpp): the walk of a handful of pairs (fastAggregateVerify: two) in half the time
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_lines_rows(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
+                                                         uint4* __restrict__ lines) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ bls_u32x4 lds[TVM_LINES_SLOTS * (TVM_SLOT_BYTES / 16)];
+    tvm_lds_char* item = (tvm_lds_char*)(tvm_lds_u32x4*)lds;
+    const row_ctx RC = row_ctx_make();
+    const uint32_t t = threadIdx.x;
+    const size_t i = (size_t)first + blockIdx.x;
+    if (t < 3) tvm_st(item, (TVM_LINES_PX + t) * TVM_SLOT_BYTES, fp_reduce(soa_ld(P, stride, t, i)));
+    else if (t < 9) tvm_st(item, (TVM_LINES_PX + t) * TVM_SLOT_BYTES, fp_reduce(soa_ld(H, stride, t - 3, i)));
+    else if (t == 9) tvm_st(item, TVM_LINES_zero * TVM_SLOT_BYTES, fp_zero());
+    __syncthreads();
+    const bool skip = tvm_slot_is_zero(item, TVM_LINES_PZ) | (tvm_slot_is_zero(item, TVM_LINES_QZ) & tvm_slot_is_zero(item, TVM_LINES_QZ + 1));
+    rvm_run<true>(RC, item, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, tvm_line_sink{lines, stride, i, true, skip});
+    (void)count;
+#endif
 }
 
 // G1 arithmetic has a small live set (a Jacobian point is 42 registers): 256 registers, two waves per SIMD, which fill each

@@ -47,6 +47,14 @@ ROW_FN rw row_down1(const rw& a) { rw r; ROW_EACH r.l[i] = (i & 15) != 15 ? a.l[
 template <int R> ROW_FN rw row_from(const rw& a) { rw r; ROW_EACH r.l[i] = a.l[R * 16 + (i & 15)]; return r; }                    // every row takes row R's value
 ROW_FN rw row_pick(const rw& a0, const rw& a1, const rw& a2, const rw& a3) { rw r; ROW_EACH r.l[i] = (i >> 4) == 0 ? a0.l[i] : (i >> 4) == 1 ? a1.l[i] : (i >> 4) == 2 ? a2.l[i] : a3.l[i]; return r; }
 ROW_FN rw row_lanes(const int32_t (&t)[16]) { rw r; ROW_EACH r.l[i] = t[i & 15]; return r; }
+template <int K> ROW_FN rw row_xrow(const rw& a) { rw r; ROW_EACH r.l[i] = a.l[i ^ (16 * K)]; return r; }                         // the value of row (r xor K) of the wave
+ROW_FN rw row_sbyte(const rw& w, int k) { rw r; ROW_EACH r.l[i] = (int32_t)((uint32_t)w.l[i] << (24 - 8 * k)) >> 24; return r; }
+ROW_FN rw row_lo16(const rw& w) { rw r; ROW_EACH r.l[i] = (int32_t)((uint32_t)w.l[i] & 0xffffu); return r; }
+ROW_FN rw row_hi16(const rw& w) { rw r; ROW_EACH r.l[i] = (int32_t)((uint32_t)w.l[i] >> 16); return r; }
+ROW_FN rw row_splat(int32_t v) { rw r; ROW_EACH r.l[i] = v; return r; }
+ROW_FN rw row_sar64(const rw64& a, int n) { rw r; ROW_EACH { int64_t v = a.l[i] >> n; BLS_REQUIRE(v == (int32_t)v, "row_sar64: beyond 32 bits"); r.l[i] = (int32_t)v; } return r; }
+ROW_FN rw64 row_add64(const rw64& a, int64_t c) { rw64 r; ROW_EACH r.l[i] = a.l[i] + c; return r; }
+ROW_FN rw row_neg(const rw& a) { rw r; ROW_EACH r.l[i] = -a.l[i]; return r; }
 ROW_FN rw row_load(const uint32_t* w) { rw r; ROW_EACH r.l[i] = (i & 15) < FP_N ? (int32_t)w[i & 15] : 0; return r; }             // an Fp value stored as 14 words
 ROW_FN void row_store(uint32_t* w, const rw& a) { for (int i = 0; i < FP_N; i++) w[i] = (uint32_t)a.l[i]; }                      // row 0's
 ROW_FN rw row_from_fp(const fp& v) { rw r; for (int i = 0; i < 64; i++) r.l[i] = (i & 15) < FP_N ? (int32_t)v.l[i & 15] : 0; return r; }
@@ -83,6 +91,14 @@ ROW_FN rw row_pick(rw a0, rw a1, rw a2, rw a3) {
     const uint32_t r = (threadIdx.x >> 4) & 3u;
     return r == 0 ? a0 : (r == 1 ? a1 : (r == 2 ? a2 : a3));
 }
+template <int K> ROW_FN rw row_xrow(rw a) { return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ (16u * K)) << 2), a); }
+ROW_FN rw row_sbyte(rw w, int k) { return (rw)((uint32_t)w << (24 - 8 * k)) >> 24; }
+ROW_FN rw row_lo16(rw w) { return (rw)((uint32_t)w & 0xffffu); }
+ROW_FN rw row_hi16(rw w) { return (rw)((uint32_t)w >> 16); }
+ROW_FN rw row_splat(int32_t v) { return v; }
+ROW_FN rw row_sar64(rw64 a, int n) { return (rw)(a >> n); }
+ROW_FN rw64 row_add64(rw64 a, int64_t c) { return a + c; }
+ROW_FN rw row_neg(rw a) { return -a; }
 ROW_FN rw row_lanes(const int32_t (&t)[16]) {
     const uint32_t l = threadIdx.x & 15u;
     rw r = 0;
@@ -119,6 +135,7 @@ struct row_ctx {
     rw nmaskv;            // the bits above 2^28 of lanes 0..12, nothing elsewhere
     rw lane13;            // all ones in lane 13
     rw live;              // all ones in lanes 0..13
+    rw low13;             // all ones in lanes 0..12 (the limbs that pass a carry on)
 };
 template <int K>
 ROW_FN void row_ctx_fill(row_ctx& C, const rw& p) {
@@ -126,13 +143,14 @@ ROW_FN void row_ctx_fill(row_ctx& C, const rw& p) {
     if constexpr (K + 1 < FP_N) row_ctx_fill<K + 1>(C, p);
 }
 ROW_FN row_ctx row_ctx_make() {
-    int32_t P16[16], M[16], NM[16], L13[16], LV[16];
+    int32_t P16[16], M[16], NM[16], L13[16], LV[16], LO[16];
     for (int i = 0; i < 16; i++) {
         P16[i] = i < FP_N ? (int32_t)k::P[i] : 0;
         M[i] = i < FP_N - 1 ? (int32_t)FP_MASK : (i == FP_N - 1 ? -1 : 0);
         NM[i] = i < FP_N - 1 ? (int32_t)~FP_MASK : 0;
         L13[i] = i == FP_N - 1 ? -1 : 0;
         LV[i] = i < FP_N ? -1 : 0;
+        LO[i] = i < FP_N - 1 ? -1 : 0;
     }
     row_ctx C;
     row_ctx_fill<0>(C, row_lanes(P16));
@@ -140,6 +158,7 @@ ROW_FN row_ctx row_ctx_make() {
     C.nmaskv = row_lanes(NM);
     C.lane13 = row_lanes(L13);
     C.live = row_lanes(LV);
+    C.low13 = row_lanes(LO);
     return C;
 }
 

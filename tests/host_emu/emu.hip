@@ -10,6 +10,7 @@
 #include "teamvm.hpp"
 #define BLS_ROW_EMU 1                    // rowfp.hpp on 64 emulated lanes
 #include "rowfp.hpp"
+#include "rowvm.hpp"
 using namespace bls;
 static rw emu_row_of4(const uint8_t* p192) { return row_pick(row_from_fp(fp_load_le(p192)), row_from_fp(fp_load_le(p192 + 48)), row_from_fp(fp_load_le(p192 + 96)), row_from_fp(fp_load_le(p192 + 144))); }
 static void emu_row_to4(uint8_t* r192, const rw& x) {
@@ -72,6 +73,37 @@ int emu_tvm_lines_equal(const uint8_t* p144, const uint8_t* q288) {
     for (int j = 0; j < 3; j++) { S[TVM_LINES_QX + 2 * j] = fp_reduce(in[j]->c0); S[TVM_LINES_QX + 2 * j + 1] = fp_reduce(in[j]->c1); }
     int same = 1, seen = 0;
     tvm_run_host(S, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, [&](uint32_t step, uint32_t plane, const fp& v) {
+        const fp2* l[3] = {&ref[step].l0, &ref[step].l1, &ref[step].l2};
+        same &= fp_eq(v, (plane & 1) ? l[plane >> 1]->c1 : l[plane >> 1]->c0) ? 1 : 0;
+        seen++;
+    });
+    return same && seen == N_LINES * 6;
+}
+// the same two programs on the ROW executor (csrc/rowvm.hpp): sixteen rows = four emulated waves per round
+void emu_rvm_clear(const uint8_t* q576, uint8_t* out288) {
+    static fp S[TVM_CLEAR_SLOTS];
+    for (auto& v : S) v = fp_zero();
+    g2_jac q0 = g2_jac_load(q576), q1 = g2_jac_load(q576 + 288);
+    const fp2* in[6] = {&q0.x, &q0.y, &q0.z, &q1.x, &q1.y, &q1.z};
+    for (int j = 0; j < 6; j++) { S[TVM_CLEAR_X + 2 * j] = fp_reduce(in[j]->c0); S[TVM_CLEAR_X + 2 * j + 1] = fp_reduce(in[j]->c1); }
+    const fp2 cx = fp2_from_const(k::PSI_CX), cy = fp2_from_const(k::PSI_CY);
+    S[TVM_CLEAR_CX] = fp_reduce(cx.c0); S[TVM_CLEAR_CX + 1] = fp_reduce(cx.c1); S[TVM_CLEAR_CY] = fp_reduce(cy.c0); S[TVM_CLEAR_CY + 1] = fp_reduce(cy.c1);
+    rvm_run_host(S, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, [](uint32_t, uint32_t, const fp&) {});
+    g2_jac_store(out288, g2_jac{fp2{S[TVM_CLEAR_X], S[TVM_CLEAR_X + 1]}, fp2{S[TVM_CLEAR_Y], S[TVM_CLEAR_Y + 1]}, fp2{S[TVM_CLEAR_Z], S[TVM_CLEAR_Z + 1]}});
+}
+// the 68 lines of one pair from the engine's walk against pairing.hpp's miller_lines: 1 = every coefficient equal mod p
+int emu_rvm_lines_equal(const uint8_t* p144, const uint8_t* q288) {
+    g1_jac pj = g1_jac_load(p144);
+    g2_jac qj = g2_jac_load(q288);
+    line_t ref[N_LINES];
+    miller_lines(pj, qj, [&](int s, const line_t& l) { ref[s] = l; });
+    static fp S[TVM_LINES_SLOTS];
+    for (auto& v : S) v = fp_zero();
+    S[TVM_LINES_PX] = fp_reduce(pj.x); S[TVM_LINES_PY] = fp_reduce(pj.y); S[TVM_LINES_PZ] = fp_reduce(pj.z);
+    const fp2* in[3] = {&qj.x, &qj.y, &qj.z};
+    for (int j = 0; j < 3; j++) { S[TVM_LINES_QX + 2 * j] = fp_reduce(in[j]->c0); S[TVM_LINES_QX + 2 * j + 1] = fp_reduce(in[j]->c1); }
+    int same = 1, seen = 0;
+    rvm_run_host(S, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, [&](uint32_t step, uint32_t plane, const fp& v) {
         const fp2* l[3] = {&ref[step].l0, &ref[step].l1, &ref[step].l2};
         same &= fp_eq(v, (plane & 1) ? l[plane >> 1]->c1 : l[plane >> 1]->c0) ? 1 : 0;
         seen++;

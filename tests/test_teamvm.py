@@ -63,37 +63,52 @@ def _jac_bytes(p, z):
     return b"".join(o.fp_to_mont_bytes(c) for c in (x[0], x[1], y[0], y[1], z[0], z[1]))
 
 
-def test_engine_clears_cofactor_like_the_oracle(emu):
-    """tvm_run_host (bounds tracker on: every product's and every reduction's preconditions are asserted) on random pairs of E2 points"""
+import pytest
+
+
+@pytest.fixture(params=["tvm", "rvm"])
+def engine(request, emu):
+    """the same programs on the lane-team executor (teamvm.hpp: a lane per product) and on the row executor (rowvm.hpp: a DPP row per product)"""
+    class E:
+        clear = getattr(emu, "emu_%s_clear" % request.param)
+        lines_equal = getattr(emu, "emu_%s_lines_equal" % request.param)
+    return E
+
+
+def test_engine_clears_cofactor_like_the_oracle(engine):
+    """tvm_run_host / rvm_run_host (bounds tracker on: every product's and every reduction's preconditions are asserted) on random pairs of E2 points"""
+    emu = engine
     rng = random.Random(17)
     for _ in range(3):
         pts = [o.iso3_g2(o.sswu_g2((rng.randrange(o.P), rng.randrange(o.P)))) for _ in range(2)]
         zs = [(rng.randrange(1, o.P), rng.randrange(o.P)) for _ in range(2)]
         out = buf(288)
-        emu.emu_tvm_clear(_jac_bytes(pts[0], zs[0]) + _jac_bytes(pts[1], zs[1]), out)
+        emu.clear(_jac_bytes(pts[0], zs[0]) + _jac_bytes(pts[1], zs[1]), out)
         got = g2_jac_to_affine(out.raw)
         assert got == o.clear_cofactor_g2(o.g2_add(pts[0], pts[1]))
         assert o.g2_in_subgroup(got)
 
 
-def test_engine_exceptional_additions_end_in_z_zero(emu):
+def test_engine_exceptional_additions_end_in_z_zero(engine):
     """q0 == q1, q0 == -q1, an operand at infinity: the incomplete additions must leave Z = 0 (k_clear_fix / k_hash_one then recompute)"""
+    emu = engine
     rng = random.Random(19)
     a = o.iso3_g2(o.sswu_g2((rng.randrange(o.P), rng.randrange(o.P))))
     z = (rng.randrange(1, o.P), rng.randrange(o.P))
     for q0, q1 in ((_jac_bytes(a, z), _jac_bytes(a, (5, 7))), (_jac_bytes(a, z), _jac_bytes(o.g2_neg(a), (3, 1))), (bytes(288), _jac_bytes(a, z)),
                    (_jac_bytes(a, z), bytes(288))):
         out = buf(288)
-        emu.emu_tvm_clear(q0 + q1, out)
+        emu.clear(q0 + q1, out)
         assert out.raw[192:288] == bytes(96)
 
 
-def test_engine_lines_equal_miller_lines(emu):
+def test_engine_lines_equal_miller_lines(engine):
+    emu = engine
     rng = random.Random(23)
     for _ in range(2):
         p = o.g1_mul(o.G1_GEN, rng.randrange(1, o.R))
         q = o.g2_mul(o.G2_GEN, rng.randrange(1, o.R))
         zp = rng.randrange(1, o.P)
         pj = b"".join(o.fp_to_mont_bytes(c) for c in (p[0] * zp * zp % o.P, p[1] * zp * zp * zp % o.P, zp))
-        assert emu.emu_tvm_lines_equal(pj, _jac_bytes(q, (rng.randrange(1, o.P), rng.randrange(o.P)))) == 1
-    assert emu.emu_tvm_lines_equal(g1_aff_to_jac_bytes(o.G1_GEN), _jac_bytes(o.G2_GEN, (1, 0))) == 1
+        assert emu.lines_equal(pj, _jac_bytes(q, (rng.randrange(1, o.P), rng.randrange(o.P)))) == 1
+    assert emu.lines_equal(g1_aff_to_jac_bytes(o.G1_GEN), _jac_bytes(o.G2_GEN, (1, 0))) == 1
