@@ -646,7 +646,8 @@ def main():
 
 
 HOT_KERNELS = ("k_hash_map", "k_hash_clear", "k_pkmul", "k_lines", "k_lineprod", "k_sig_bucket")
-LATENCY_KERNELS = ("k_hash_one", "k_team_clear", "k_team_clear_spread", "k_team_lines", "k_team_lines_spread", "k_tail", "k_fold")
+LATENCY_KERNELS = ("k_hash_one", "k_hash_map_rows", "k_team_clear", "k_team_clear_spread", "k_team_clear_rows", "k_team_lines", "k_team_lines_spread", "k_team_lines_rows",
+                   "k_pip_rowtail", "k_tail", "k_fold")
 
 
 def kernel_meta():

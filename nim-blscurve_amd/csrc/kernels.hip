@@ -673,8 +673,7 @@ __device__ __forceinline__ void team_clear_body(const uint4* __restrict__ M, siz
 #endif
 }
 // Small batches (a few hundred messages at most): the engine's program on the ROW executor, a workgroup of four waves per message (rowvm.hpp)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_team_clear_rows(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+__device__ __forceinline__ void team_clear_rows_body(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[TVM_CLEAR_SLOTS * (TVM_SLOT_BYTES / 16)];
     tvm_lds_char* item = (tvm_lds_char*)(tvm_lds_u32x4*)lds;
@@ -692,7 +691,17 @@ k_team_clear_rows(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4
     rvm_run<false>(RC, item, TVM_CLEAR_DESC, TVM_CLEAR_SEQ, TVM_CLEAR_NSEQ, tvm_line_sink{});
     // partially reduced, canonical limbs on the way out: k_clear_fix (behind this kernel) finds the exceptional cases by Z = 0
     if (t < 6) soa_st(H, stride, t, i, fp_reduce(tvm_ld(item, (TVM_CLEAR_X + t) * TVM_SLOT_BYTES)));
+    (void)n;
 #endif
+}
+// one workgroup per CU (a wave per SIMD) up to 224 items; two per CU - two waves take turns on a SIMD, each ~1.4 x as long - up to 448
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_clear_rows(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    team_clear_rows_body(M, mstride, n, H, stride);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_team_clear_rows2(const uint4* __restrict__ M, size_t mstride, uint32_t n, uint4* __restrict__ H, size_t stride) {
+    team_clear_rows_body(M, mstride, n, H, stride);
 }
 // Two forms of each engine kernel, same code.  The plain one: ~100 registers, a SIMD takes several waves - for grids beyond one wave per SIMD.
 // The SPREAD one declares a whole SIMD's register file (amdgpu_waves_per_eu(1, 1): the register count in the kernel descriptor is raised to
@@ -741,9 +750,8 @@ k_team_lines_spread(const uint4* __restrict__ P, const uint4* __restrict__ H, ui
     team_lines_body(P, H, first, count, stride, lines);
 }
 // a workgroup of four waves per pair (rowvm.hpp): the walk of a handful of pairs (fastAggregateVerify: two) in half the time
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_team_lines_rows(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
-                                                         uint4* __restrict__ lines) {
+__device__ __forceinline__ void team_lines_rows_body(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride,
+                                                     uint4* __restrict__ lines) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ bls_u32x4 lds[TVM_LINES_SLOTS * (TVM_SLOT_BYTES / 16)];
     tvm_lds_char* item = (tvm_lds_char*)(tvm_lds_u32x4*)lds;
@@ -758,6 +766,14 @@ k_team_lines_rows(const uint4* __restrict__ P, const uint4* __restrict__ H, uint
     rvm_run<true>(RC, item, TVM_LINES_DESC, TVM_LINES_SEQ, TVM_LINES_NSEQ, tvm_line_sink{lines, stride, i, true, skip});
     (void)count;
 #endif
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_team_lines_rows(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride, uint4* __restrict__ lines) {
+    team_lines_rows_body(P, H, first, count, stride, lines);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_team_lines_rows2(const uint4* __restrict__ P, const uint4* __restrict__ H, uint32_t first, uint32_t count, size_t stride, uint4* __restrict__ lines) {
+    team_lines_rows_body(P, H, first, count, stride, lines);
 }
 
 // G1 arithmetic has a small live set (a Jacobian point is 42 registers): 256 registers, two waves per SIMD, which fill each

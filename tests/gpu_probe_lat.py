@@ -20,9 +20,10 @@ for k in (32768, 1):
     t = gen.timings()
     print("FAV n=%d: %.2f ms verdict %d  g1sum %.2f hash+setup %.2f lines %.2f products %.2f tail %.2f" % (k, dt, r, t["blinding"], t["hash_to_g2"], t["pk_mul"], t["sig_mul_sum"], t["miller_lines"]))
 base = bench.sign_records(m, gen, dev, range(65536))
-for nn in (3, 64, 1000, 4096, 8192, 16384, 65536):
+SIZES = tuple(int(x) for x in os.environ["LAT_SIZES"].split(",")) if os.environ.get("LAT_SIZES") else (3, 64, 1000, 4096, 8192, 16384, 65536)
+for nn in SIZES:
     c = m.BatchedBLSVerifierCache.init(max_sets=nn)
-    c.verify_device(base.data_ptr(), nn, rnd)
+    c.verify_device(base.data_ptr(), nn, rnd); c.verify_device(base.data_ptr(), nn, rnd)
     t0 = time.perf_counter(); ok = c.verify_device(base.data_ptr(), nn, rnd); dt = (time.perf_counter() - t0) * 1e3
     print("batch n=%d: %.2f ms %s %s %s" % (nn, dt, ok, {k: round(v, 2) for k, v in c.timings().items()}, {k: round(v, 2) for k, v in c.kernel_timings().items()}))
     c.close()

@@ -254,6 +254,25 @@ def test_bucket_fold_of_the_signature_side(m, n):
     cache.close()
 
 
+@pytest.mark.parametrize("n", [63, 64, 223, 224, 225, 1792, 1793])
+def test_hand_over_sizes_of_the_row_executor(m, n):
+    """Around the sizes where the latency path changes executor (csrc/rowvm.hpp: a workgroup of four waves per message / pair up to 224 items, the
+    lane-team engine above; k_hash_map_rows: a (message, u) pair per DPP row up to 1 792 messages; the signature side's buckets become extra pairs from
+    64 sets): the verdict AND the GT value of the C restatement, valid batch and one with a wrong signature."""
+    import c_oracle as co
+    rec = bytearray(co.make_batch(n, seed=777 + n))
+    rnd = o.sha256(b"Mr F was here")
+    cache = m.BatchedBLSVerifierCache.init(max_sets=n, numThreads=7)
+    assert m.batchVerifyParallel(cache, bytes(rec), rnd) is True
+    ok, st = co.batch_verify(bytes(rec), rnd, 7, stages=True)
+    assert ok and cache.fetch(4, 576) == st["gt"]
+    rec[320 * (n // 2) + 128:320 * (n // 2) + 320], rec[128:320] = rec[128:320], rec[320 * (n // 2) + 128:320 * (n // 2) + 320]     # two signatures swapped
+    assert m.batchVerifyParallel(cache, bytes(rec), rnd) is False
+    ok, st = co.batch_verify(bytes(rec), rnd, 7, stages=True)
+    assert not ok and cache.fetch(4, 576) == st["gt"]
+    cache.close()
+
+
 @pytest.mark.parametrize("n", [65537, 100003, 131072])
 def test_sizes_beyond_one_wave_per_simd(m, n):
     """More than 64 x 1024 tuples (several rounds of waves, side-stream path on/off): all-valid -> true,
