@@ -988,6 +988,7 @@ constexpr int C12_NREG = 8;
 // Threads of the engine's workgroup: three waves in both context modes.  Phase 1 runs the 144 Fp products of an Fp12 multiplication
 // one per thread, phase 2 (c12_phase2_rows) owns one output limb per thread as 12 rows of 16 lanes - it REQUIRES blockDim.x == 192.
 constexpr int TAIL_THREADS = 192, TAIL_THREADS_TP = 192;
+constexpr int K_TAIL_THREADS = 320;                  // k_tail: the engine's three waves + two: eighteen (+ two idle) rows for the cyclotomic squarings on rows
 static_assert(TAIL_THREADS == 192 && TAIL_THREADS_TP == 192, "c12_phase2_rows: 12 coefficient rows of 16 lanes");
 struct c12_lds {
     fp2 r[C12_NREG][6];
@@ -1019,6 +1020,7 @@ __device__ __forceinline__ int32_t c12_shr1(int32_t v) { return __builtin_amdgcn
 template <bool SQR, class LDS>
 __device__ __forceinline__ void c12_phase2_rows(LDS& S, int d) {
     const int t = threadIdx.x, c = t >> 4, l = t & 15;
+    if (t >= 12 * 16) return;                                              // k_tail brings two more waves for the cyclotomic squarings (c12_cyc_sqr_rows)
     const bool live = l < FP_N;
     const int ll = live ? l : 0;
     const int32_t pl = S.w.pl[l];                                          // issued with the other LDS reads, used at the end
@@ -1172,12 +1174,60 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_state_mul(uint32_t* __restrict
     c12_store(S, 0, states + (size_t)dst * 144);
 }
 
-// d = a^x (x < 0, a cyclotomic): square-and-multiply over |x|, then conjugate.  tmp != a.
+// n squarings in place of register `slot`, which holds a UNITARY value (the hard part of the final exponentiation): Granger-Scott on row arithmetic
+// (rowcyc.hpp) - rows 0 .. 17 of the block form the eighteen Fp products along their sixteen lanes, rows 0 .. 11 the new coefficients; two barriers per
+// squaring, ~0.7 us where the engine's generic square takes ~2.2.  The block needs 18 rows (288 lanes); the products wait in the engine's product area.
+struct cyc_mem_lds {
+    c12_lds& S;
+    int slot;
+    uint32_t* pw;
+    __device__ __forceinline__ rw coef(int j, int comp) const {
+        const uint32_t l = threadIdx.x & 15u;
+        const fp& f = comp ? S.r[slot][j].c1 : S.r[slot][j].c0;
+        const uint32_t v = f.l[l < (uint32_t)FP_N ? l : 0u];
+        return l < (uint32_t)FP_N ? (rw)v : 0;
+    }
+    __device__ __forceinline__ rw prod(int r) const { return (rw)pw[r * 16 + (threadIdx.x & 15u)]; }
+};
+__device__ __noinline__ void c12_cyc_sqr_rows(c12_lds& S, int slot, int n) {
+    const row_ctx C = row_ctx_make();
+    const int row = (int)(threadIdx.x >> 4), l16 = (int)(threadIdx.x & 15u);
+    uint32_t* pw = reinterpret_cast<uint32_t*>(S.w.prod);
+    const cyc_mem_lds mem{S, slot, pw};
+    const cyc_out_row t = cyc_out_of(row < 12 ? row : 0);
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < n; i++) {
+        if (row < 18) pw[row * 16 + l16] = (uint32_t)cyc_product_row(C, mem, row);
+        __syncthreads();
+        if (row < 12) {
+            const rw o = cyc_output_row(C, mem, row, t);
+            fp2& dst = S.r[slot][row >> 1];
+            if (l16 < FP_N) ((row & 1) ? dst.c1 : dst.c0).l[l16] = (uint32_t)o;
+        }
+        __syncthreads();
+    }
+}
+// d = a^x (x < 0, a cyclotomic): square-and-multiply over |x|, then conjugate.  tmp != a.  ROWS (k_tail_rows: a block of 20 rows) takes the runs of
+// squarings between the set bits of |x| on row arithmetic.
+template <bool ROWS>
 __device__ __noinline__ void c12_cyc_exp_x(c12_lds& S, int d, int a, int tmp) {
     c12_copy(S, tmp, a);
-    for (int bit = 62; bit >= 0; bit--) {
-        c12_sqr(S, tmp, tmp);
-        if ((k::X_ABS >> bit) & 1) c12_mul(S, tmp, tmp, a);
+    if constexpr (ROWS) {
+        int pending = 0;
+        for (int bit = 62; bit >= 0; bit--) {
+            pending++;
+            if ((k::X_ABS >> bit) & 1) {
+                c12_cyc_sqr_rows(S, tmp, pending);
+                pending = 0;
+                c12_mul(S, tmp, tmp, a);
+            }
+        }
+        if (pending) c12_cyc_sqr_rows(S, tmp, pending);
+    } else {
+        for (int bit = 62; bit >= 0; bit--) {
+            c12_sqr(S, tmp, tmp);
+            if ((k::X_ABS >> bit) & 1) c12_mul(S, tmp, tmp, a);
+        }
     }
     c12_conj(S, d, tmp);
 }
@@ -1200,7 +1250,8 @@ __device__ __noinline__ void c12_inv(c12_lds& S, int d, int a, int t1, int t2) {
 // bit 1: multiply the kk states and run the final exponentiation -> gt_out, verdict.
 // sstride: distance in words between the kk states (144 = packed blst_fp12 images); blob != 0: every state is followed by
 // its shard's ok word (1 = no update failed), and the verdict also requires all of them.
-__global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
+template <bool ROWS>
+__device__ __forceinline__ void tail_body(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
                                                        uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
     __shared__ c12_lds S;
     int lane = threadIdx.x;
@@ -1250,17 +1301,17 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
         c12_frob2(S, X1, T);
         c12_mul(S, T, X1, T);
         // hard part: 3(p^4-p^2+1)/r = (x-1)^2 (x+p)(x^2+p^2-1) + 3
-        c12_cyc_exp_x(S, X1, T, X3);            // t^x
+        c12_cyc_exp_x<ROWS>(S, X1, T, X3);            // t^x
         c12_conj(S, X2, T);
         c12_mul(S, A, X1, X2);                  // a = t^(x-1)
-        c12_cyc_exp_x(S, X1, A, X3);
+        c12_cyc_exp_x<ROWS>(S, X1, A, X3);
         c12_conj(S, X2, A);
         c12_mul(S, A, X1, X2);                  // a = t^((x-1)^2)
-        c12_cyc_exp_x(S, X1, A, X3);
+        c12_cyc_exp_x<ROWS>(S, X1, A, X3);
         c12_frob(S, X2, A);
         c12_mul(S, B, X1, X2);                  // b = a^(x+p)
-        c12_cyc_exp_x(S, X1, B, X3);
-        c12_cyc_exp_x(S, X2, X1, X3);           // b^(x^2)
+        c12_cyc_exp_x<ROWS>(S, X1, B, X3);
+        c12_cyc_exp_x<ROWS>(S, X2, X1, X3);           // b^(x^2)
         c12_frob2(S, X1, B);
         c12_mul(S, C, X2, X1);
         c12_conj(S, X1, B);
@@ -1290,6 +1341,17 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restric
                (hwid >> 8) & 15, (hwid >> 13) & 7, hwid, ldsa & 0xff, (ldsa >> 12) & 0x1ff, ldsa);
     }
 #endif
+}
+// Two forms: k_tail - the engine's three waves, as rounds 3 - 5 (throughput-mode contexts: a block of five waves needs a CU with four free SIMDs at once and
+// was measured 0.3 ms per batch SLOWER under three batches in flight); k_tail_rows - two more waves, the cyclotomic squarings of the final exponentiation
+// on row arithmetic (latency-mode contexts: every blocking call 0.3 ms shorter, profiles/r06_ab/ab_rowcyc.txt).
+__global__ void __launch_bounds__(TAIL_THREADS) k_tail(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
+                                                       uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
+    tail_body<false>(L, states, kk, mode, gt_out, verdict, sstride, blob);
+}
+__global__ void __launch_bounds__(K_TAIL_THREADS) k_tail_rows(const uint32_t* __restrict__ L, uint32_t* __restrict__ states, uint32_t kk, int mode,
+                                                       uint32_t* __restrict__ gt_out, uint32_t* __restrict__ verdict, uint32_t sstride, int blob) {
+    tail_body<true>(L, states, kk, mode, gt_out, verdict, sstride, blob);
 }
 
 // ------------------------------------------------------------------------------------------

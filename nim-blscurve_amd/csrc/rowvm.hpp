@@ -6,7 +6,7 @@
 // (fastAggregateVerify, one signature, small batches): four waves per item instead of a quarter of one.
 // The round body is written on `rw` (rowfp.hpp): the device runs it per lane, tests/host_emu on 64 emulated lanes per wave with every bound asserted.
 #pragma once
-#include "rowfp.hpp"
+#include "rowcyc.hpp"
 #include "teamvm.hpp"
 
 namespace bls {
@@ -23,12 +23,9 @@ ROW_FN rw rvm_post(const row_ctx& C, const rw& v, const rw& t, const rvm_desc& d
     acc = row_mad(v2, row_sbyte(d.z, 2), acc);
     acc = row_mad(v3, row_sbyte(d.z, 3), acc);
     acc = row_mad(t, row_sbyte(d.w, 0), acc);
-    // quotient from the top limb (fp_reduce's estimate: the limbs below add less than 2^-10 p to a value of at most 66 p)
-    const rw top = row_bcast<FP_N - 1>(row_lo(acc));
-    const rw nq = row_neg(row_sar64(row_add64(row_mad(top, row_splat(10322735), row_zero64()), (int64_t)1 << 39), 40));
-    acc = row_mad(nq, C.prot[0], acc);
-    // one linear carry pass from the 64-bit sums (|.| < 2^36): the top limb keeps what is above it
-    rw x = (row_lo(acc) & C.maskv) + row_up1(row_hi28(acc) & C.low13);
+    // quotient from the top limb (fp_reduce's estimate: the limbs below add less than 2^-10 p to a value of at most 66 p), one linear carry pass from the
+    // 64-bit sums (|.| < 2^36): the top limb keeps what is above it
+    rw x = row_reduce64(C, acc);
     if (tight) x = row_norm(C, x);
     return x;
 }

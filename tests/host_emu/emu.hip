@@ -261,6 +261,36 @@ void emu_c12_rowphase(const uint8_t* a576, const uint8_t* b576, int sqr, uint8_t
     for (int t = 0; t < 6; t++) *tr[t] = D[c12_flat_of_tower(t)];
     fp12_store_le(out576, r);
 }
+// n Granger-Scott squarings of a UNITARY Fp12 value on row arithmetic (csrc/rowcyc.hpp: what c12_cyc_sqr_rows does between its barriers): eighteen
+// product rows, twelve output rows, every bound asserted
+struct emu_cyc_mem {
+    const fp2* A;           // the value, flat basis
+    const rw* P;            // the eighteen products
+    rw coef(int j, int comp) const { return row_from_fp(comp ? A[j].c1 : A[j].c0); }
+    rw prod(int r) const { return P[r]; }
+};
+void emu_cyc_sqr(const uint8_t* a576, int n, uint8_t* out576) {
+    fp12 fa = fp12_load_le(a576);
+    const fp2* ta[6] = {&fa.c0.a0, &fa.c0.a1, &fa.c0.a2, &fa.c1.a0, &fa.c1.a1, &fa.c1.a2};
+    fp2 A[6];
+    for (int t = 0; t < 6; t++) A[c12_flat_of_tower(t)] = fp2_reduce(*ta[t]);
+    const row_ctx C = row_ctx_make();
+    for (int it = 0; it < n; it++) {
+        rw P[18];
+        for (int r = 0; r < 18; r++) P[r] = cyc_product_row(C, emu_cyc_mem{A, P}, r);
+        fp2 D[6];
+        for (int o = 0; o < 12; o++) {
+            fp v = row_to_fp(cyc_output_row(C, emu_cyc_mem{A, P}, o, cyc_out_of(o)));
+            BLS_SET_VB(v, 1); BLS_SET_LB(v, 1);
+            if (o & 1) D[o >> 1].c1 = v; else D[o >> 1].c0 = v;
+        }
+        for (int j = 0; j < 6; j++) A[j] = D[j];
+    }
+    fp12 r;
+    fp2* tr[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
+    for (int t = 0; t < 6; t++) *tr[t] = A[c12_flat_of_tower(t)];
+    fp12_store_le(out576, r);
+}
 void emu_c12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { emu_c12_rowphase(a, b, 0, out); }
 void emu_c12_sqr(const uint8_t* a, uint8_t* out) { emu_c12_rowphase(a, a, 1, out); }
 }

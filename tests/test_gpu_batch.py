@@ -254,10 +254,10 @@ def test_bucket_fold_of_the_signature_side(m, n):
     cache.close()
 
 
-@pytest.mark.parametrize("n", [63, 64, 223, 224, 225, 1792, 1793])
+@pytest.mark.parametrize("n", [63, 64, 223, 224, 225, 447, 448, 449, 1792, 1793])
 def test_hand_over_sizes_of_the_row_executor(m, n):
-    """Around the sizes where the latency path changes executor (csrc/rowvm.hpp: a workgroup of four waves per message / pair up to 224 items, the
-    lane-team engine above; k_hash_map_rows: a (message, u) pair per DPP row up to 1 792 messages; the signature side's buckets become extra pairs from
+    """Around the sizes where the latency path changes executor (csrc/rowvm.hpp: a workgroup of four waves per message / pair, one per CU up to 224 items, two
+    per CU up to 448, the lane-team engine above; k_hash_map_rows: a (message, u) pair per DPP row up to 1 792 messages; the signature side's buckets become extra pairs from
     64 sets): the verdict AND the GT value of the C restatement, valid batch and one with a wrong signature."""
     import c_oracle as co
     rec = bytearray(co.make_batch(n, seed=777 + n))

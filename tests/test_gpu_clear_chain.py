@@ -30,7 +30,7 @@ def _jac_bytes(p, z):
     return b"".join(o.fp_to_mont_bytes(c) for c in (x[0], x[1], y[0], y[1], z[0], z[1]))
 
 
-@pytest.mark.parametrize("mode", ["throughput", "latency", "latency_team"])
+@pytest.mark.parametrize("mode", ["throughput", "latency", "latency_rows2", "latency_team"])
 def test_clear_cofactor_of_arbitrary_pairs(m, mode):
     rng = random.Random(3)
 
@@ -43,11 +43,13 @@ def test_clear_cofactor_of_arbitrary_pairs(m, mode):
     pairs = [(e2_point(), e2_point()) for _ in range(70)]
     a, b = e2_point(), e2_point()
     pairs += [(a, None), (None, b), (None, None), (a, a), (a, o.g2_neg(a)), (o.G2_GEN, o.g2_mul(o.G2_GEN, 2))]
-    if mode == "latency_team":                      # beyond what the row executor takes (four waves per message): the lane-team engine, a message per 16 lanes
+    if mode == "latency_rows2":                     # 304 pairs: the row executor at two workgroups per CU
         pairs = pairs * 4
+    if mode == "latency_team":                      # 456 pairs, beyond what the row executor takes (four waves per message): the lane-team engine, a message per 16 lanes
+        pairs = pairs * 6
     blob = b"".join(_jac_bytes(p, z()) + _jac_bytes(q, z()) for p, q in pairs)
     out = ctypes.create_string_buffer(288 * len(pairs))
-    cache = m.BatchedBLSVerifierCache.init(max_sets=512)
+    cache = m.BatchedBLSVerifierCache.init(max_sets=1024)
     cache.set_cooperative(mode != "throughput")     # latency: the engine's programs on rows (k_team_clear_rows) or lane teams (k_team_clear); throughput: k_hash_clear
     assert m._check(m.lib().mi355_bls_debug_g2_clear_cofactor(cache._h, blob, len(pairs), out)) == 0
     for i, (p, q) in enumerate(pairs):

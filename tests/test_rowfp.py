@@ -4,7 +4,7 @@ The GPU parity tests of the MSM (tests/test_gpu_msm.py, test_gpu_headline.py) ru
 import random
 
 import bls12381_py as o
-from util import buf, g1_aff_to_jac_bytes, g1_jac_to_affine
+from util import buf, fp12_from_bytes, fp12_to_bytes, g1_aff_to_jac_bytes, g1_jac_to_affine
 
 
 def _mont(v):
@@ -67,3 +67,21 @@ def test_row_exponentiation_of_the_square_root(emu):
         emu.emu_row_pow(b"".join(map(_mont, a)), out)
         got = [o.fp_from_mont_bytes(out.raw[48 * i:48 * i + 48]) for i in range(4)]
         assert got == [pow(x, (o.P - 3) // 4, o.P) for x in a]
+
+
+def test_cyclotomic_squarings_on_rows(emu):
+    """the final exponentiation's squarings by |x| (csrc/rowcyc.hpp: Granger-Scott in the flat basis, eighteen products along rows) on unitary values"""
+    rng = random.Random(9)
+    for n in (1, 2, 9, 32):
+        f = tuple((rng.randrange(o.P), rng.randrange(o.P)) for _ in range(6))
+        t = o.f12mul(o.f12conj(f), o.f12inv(f))              # the easy part of the final exponentiation makes it unitary
+        t = o.f12mul(o.f12frob_n(t, 2), t)
+        out = buf(576)
+        emu.emu_cyc_sqr(fp12_to_bytes(t), n, out)
+        want = t
+        for _ in range(n):
+            want = o.f12sqr(want)
+        assert fp12_from_bytes(out.raw) == want
+    out = buf(576)
+    emu.emu_cyc_sqr(fp12_to_bytes(o.F12_ONE), 5, out)
+    assert fp12_from_bytes(out.raw) == o.F12_ONE
