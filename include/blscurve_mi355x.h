@@ -81,8 +81,8 @@ int mi355_bls_ctx_set_cooperative(mi355_bls_ctx* ctx, int on);
 
 /* batchVerifyParallel / batchVerify raw-pointer overloads (bls_batch_verifier.nim:296-302,420-426):
  * sets = n x 320-byte SignatureSet records in HOST memory, rnd = secureRandomBytes. n == 0 -> 0.
- * WHEN TO CALL IT: one blocking call costs about 2.6 ms for any n up to ~200 and 3.2 ms up to ~1 000 (latency-bound chains: hash-to-G2,
- * Miller walk, final exponentiation), 3.9 ms at 4 096, 12.5 ms at 65 536 (11 ms per batch when three are kept in flight).  A CPU BLST verifies a small
+ * WHEN TO CALL IT: one blocking call costs about 2.3 ms for any n up to ~200 and 3.0 ms up to ~1 000 (latency-bound chains: hash-to-G2,
+ * Miller walk, final exponentiation), 3.5 ms at 4 096, 12.4 ms at 65 536 (11 ms per batch when three are kept in flight).  A CPU BLST verifies a small
  * batch faster than that: below about 5 sets per host core (~80 sets on 16 cores; bench.py's `crossover`, INTEGRATION.md "When to call the
  * GPU") a host should keep its CPU path, as the Nim shim of INTEGRATION.md does (Mi355MinSets).  Many small batches at once:
  * mi355_bls_batch_verify_many. */
