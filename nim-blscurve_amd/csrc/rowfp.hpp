@@ -162,19 +162,25 @@ ROW_FN row_ctx row_ctx_make() {
     return C;
 }
 
+// (the operands of step K + 1 - a broadcast and a rotation that depend on nothing in the chain - are formed right behind step K's first multiply-add, where the
+// DPP read of the fresh accumulator would otherwise wait two states)
 template <int K>
-ROW_FN void row_mul_step(const row_ctx& C, const rw& a, const rw& b, rw64& acc) {
-    acc = row_mad(row_bcast<K>(a), row_ror<K>(b), acc);                           // column l (or l + 16) += a_K * b_(l - K)
+ROW_FN void row_mul_step(const row_ctx& C, const rw& a, const rw& b, const rw& ak, const rw& bk, rw64& acc) {
+    acc = row_mad(ak, bk, acc);                                                   // column l (or l + 16) += a_K * b_(l - K)
+    constexpr int K1 = K + 1 < FP_N ? K + 1 : K;
+    const rw ak1 = row_bcast<K1>(a), bk1 = row_ror<K1>(b);
     const rw m = row_and(row_mullo(row_bcast<K>(row_lo(acc)), k::N0), FP_MASK);   // column K's Montgomery digit, in every lane
     acc = row_mad(m, C.prot[K], acc);                                             // column K is now a multiple of 2^28
-    acc = row_ext(row_and(row_lo(acc), FP_MASK) + row_ror<1>(row_hi28(acc)));     // every lane keeps 28 bits and takes its neighbour's rest; lane K restarts as column K + 16
-    if constexpr (K + 1 < FP_N) row_mul_step<K + 1>(C, a, b, acc);
+    const rw hi = row_hi28(acc);                                                  // (first: the mask below then fills the wait states of the DPP read of `hi`)
+    const rw lo = row_and(row_lo(acc), FP_MASK);
+    acc = row_ext(lo + row_ror<1>(hi));                                           // every lane keeps 28 bits and takes its neighbour's rest; lane K restarts as column K + 16
+    if constexpr (K + 1 < FP_N) row_mul_step<K + 1>(C, a, b, ak1, bk1, acc);
 }
 // a * b / 2^392 mod p.  In: limbs |.| <= 2^29 + 64, lanes 14 and 15 zero.  Out: limbs 0..12 in [0, 2^28) plus a carry of at most 16 in size, limb 13 signed,
 // lanes 14, 15 zero; the value is a b / 2^392 + (0 .. 1) p.
 ROW_FN rw row_mul(const row_ctx& C, const rw& a, const rw& b) {
     rw64 acc = row_zero64();
-    row_mul_step<0>(C, a, b, acc);
+    row_mul_step<0>(C, a, b, row_bcast<0>(a), row_ror<0>(b), acc);
     // lanes 0..13 hold columns 16..29, lanes 14, 15 columns 14, 15: limb j of the result is column 14 + j
     rw r = row_ror<2>(row_lo(acc));
     r = row_and(r, FP_MASK) + row_up1(row_sar(r, 28));                            // one linear carry pass over the sixteen limbs (what leaves limb 15 is sign extension)
